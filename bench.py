@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py - Stage-1 retrieval throughput on MI355X (contract: see the task statement).
+
+Workload (BASELINE.json configs[1]): Flat inner-product search over 1M x 4096
+fp32 rows, batch-1 queries, k=10.  A "step" is one search of one query batch over
+the whole database.  With --gpus N (one rank per GPU under torch.distributed.run)
+the SAME database is row-sharded over the ranks (strong scaling): every rank
+scans N_total/N rows, the per-rank top-k lists are all-gathered over RCCL and
+merged.  Data is synthetic: N(0,1) components, L2-normalised rows, generated on
+the device; queries likewise.  Inputs are resident in HBM before timing starts.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=1_000_000, help="total database rows (sharded over --gpus)")
+    ap.add_argument("--d", type=int, default=4096)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--storage", default="f32", choices=["f32", "f16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
+    return ap.parse_args()
+
+
+def cpu_baseline(index, d, k, sample_rows, queries):
+    """C/OpenMP restatement of the oracle on a bounded sample of the same rows."""
+    from oracle import c_oracle
+    n = min(sample_rows, index.ntotal)
+    X = index.reconstruct_n(0, n)
+    Q = queries[:4].cpu().numpy()
+    c_oracle.search(X[:1000], Q[:1], k)  # load + warm
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        c_oracle.search(X, Q, k)
+        reps += 1
+        if time.perf_counter() - t0 > 10.0 or reps >= 8:
+            break
+    dt = time.perf_counter() - t0
+    qps = reps * Q.shape[0] / dt
+    return {
+        "value": qps, "unit": "queries/s", "cores": c_oracle.num_threads(), "kind": "port",
+        "sample": f"oracle/flat_ip.c (OpenMP) on the first {n} rows x {d} fp32 of the same database, "
+                  f"{reps * Q.shape[0]} batch-1 queries, k={k}; linear extrapolation to the full database "
+                  f"= value * {n}/N",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (MI355X)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from semantic_search_amd.sharded import ShardedFlatIP, shard_bounds
+
+    bounds = shard_bounds(args.n, world)
+    n_local = bounds[rank + 1] - bounds[rank]
+    index = ShardedFlatIP(args.d, storage=args.storage, device=local_rank)
+    index.add_local_random_unit(n_local, seed=1234 + rank)
+    index.finalize(device=dev)
+
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    nsets = 8  # rotate over a few query batches so no step repeats the previous one
+    Q = torch.randn((nsets, args.batch, args.d), generator=g, dtype=torch.float32)
+    Q = (Q / Q.norm(dim=-1, keepdim=True)).to(dev)
+
+    def step(i):
+        return index.search(Q[i % nsets], args.k)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: per-launch hipEvent durations recorded by the library on the launch stream
+    scan_ms = index.local.scan_times_ms(min(args.steps, 256))
+    scan_avg_ms = float(np.mean(scan_ms)) if len(scan_ms) else float("nan")
+    elsize = 4 if args.storage == "f32" else 2
+    timing = index.local.last_timing()
+    passes = max(1, timing["last_scan_bytes"] // max(1, n_local * args.d * elsize))
+    algo_bytes = n_local * args.d * elsize  # N*d*s per batch, per GPU N/G
+    algo_flops = 2.0 * args.batch * n_local * args.d
+    intensity = algo_flops / algo_bytes
+    if timing["last_path"] == 1:
+        roof = {"bound": "mfma", "achieved": algo_flops / (scan_avg_ms * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
+                "unit": "TFLOP/s"}
+    else:
+        roof = {"bound": "hbm", "achieved": algo_bytes / (scan_avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["traffic"] = None
+    roof["kernel"] = {0: "flat_scan_topk_kernel", 1: "flat_mfma_topk_kernel", 2: "ivf_scan_topk_kernel"}[timing["last_path"]]
+    roof["kernel_avg_ms"] = scan_avg_ms
+    roof["launches_timed"] = int(len(scan_ms))
+    roof["db_passes_per_launch"] = int(passes)
+    roof["flop_per_byte"] = intensity
+
+    if rank == 0:
+        qps = args.batch * args.steps / elapsed
+        line = {
+            "metric": "queries/sec at k=%d, %d-d" % (args.k, args.d),
+            "value": qps,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32" if args.storage == "f32" else "f16 storage, f32 accumulate",
+            "data": "synthetic",
+            "config": {
+                "workload": "Flat IP %dx%d %s, batch %d, k=%d (BASELINE.json configs[1]); database row-sharded over n_gpus"
+                            % (args.n, args.d, args.storage, args.batch, args.k),
+                "rows_total": args.n, "rows_per_gpu": n_local, "dim": args.d, "k": args.k, "batch": args.batch,
+                "storage": args.storage, "parallelism": "rowshard%d" % world,
+            },
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(index.local, args.d, args.k, args.cpu_sample_rows, Q[0].expand(4, -1) if args.batch == 1 else Q[0])
+            line["cpu_baseline"]["extrapolated_full_db_qps"] = line["cpu_baseline"]["value"] * min(args.cpu_sample_rows, n_local) / args.n
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+/*
+ * ssmi.h - C-ABI of libssmi.so: MI355X (gfx950) Stage-1 vector retrieval engine.
+ *
+ * This is the drop-in boundary for the one hot path this repository replaces:
+ * the calls that EricRollei/Semantic-Search makes into CPU FAISS from
+ * core/index_factory.py and core/index_manager.py.  The reference has no FFI
+ * layer of its own (it talks to the SWIG `faiss` module); each entry point
+ * below names the reference call site (file:line under the reference tree)
+ * whose FAISS call it stands in for.  The Python facade that re-creates the
+ * `faiss.Index` duck type on top of these functions lives in
+ * semantic-search_amd/faiss_compat.py; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, nonzero on failure; the message is
+ *     available from ssmi_last_error() (thread-local).  The Python facade maps
+ *     nonzero -> RuntimeError, which is what the reference catches
+ *     (core/index_factory.py:275,376; core/index_manager.py:610).
+ *   - caller owns every input/output buffer; the library copies on add.
+ *   - one handle lives on ONE GPU (one process per GPU; sharding across GPUs is
+ *     done above this ABI with torch.distributed/RCCL, see sharded.py).
+ *   - ids are implicit sequential row numbers, as with FAISS add() without ids
+ *     (core/index_manager.py:319-325); int64 on the ABI, < 2^32-1 per handle.
+ *   - short results are padded with id -1 / score -FLT_MAX, which is what the
+ *     reference filters on (core/index_manager.py:376).
+ *   - result order: score descending, ties broken by ascending id.
+ *   - calls on one handle must be serialised by the caller (the reference
+ *     holds a per-index RLock, core/index_manager.py:175); distinct handles may
+ *     be used from distinct threads.  No global mutable state besides the
+ *     thread-local error string.
+ */
+#ifndef SSMI_H
+#define SSMI_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ssmi_index ssmi_index;
+
+/* element types */
+#define SSMI_F32 0
+#define SSMI_F16 1
+/* where a caller buffer lives */
+#define SSMI_HOST 0
+#define SSMI_DEVICE 1
+/* index kinds (ssmi_index_get_kind) */
+#define SSMI_KIND_FLAT 0
+#define SSMI_KIND_IVFFLAT 1
+
+/* thread-local message of the last failing call on this thread */
+const char* ssmi_last_error(void);
+/* ABI version, bumped on incompatible change */
+int ssmi_abi_version(void);
+/* number of visible HIP devices (does not initialise a context on any) */
+int ssmi_device_count(int* out);
+
+/* ---- construction ------------------------------------------------------ */
+/* replaces faiss.IndexFlatIP(dim)                 core/index_factory.py:140 */
+int ssmi_index_create_flat(int d, int storage_dtype, int device, ssmi_index** out);
+/* replaces faiss.IndexIVFFlat(quantizer, dim, nlist, METRIC_INNER_PRODUCT)
+ *                                                  core/index_factory.py:144-146 */
+int ssmi_index_create_ivfflat(int d, int nlist, int storage_dtype, int device, ssmi_index** out);
+int ssmi_index_free(ssmi_index* h);
+
+/* ---- attributes (faiss.Index .d .ntotal .is_trained .nlist .nprobe;
+ *      core/index_factory.py:169-170,223-233,317-318) --------------------- */
+int ssmi_index_get_kind(const ssmi_index* h, int* out);
+int ssmi_index_get_d(const ssmi_index* h, int* out);
+int ssmi_index_get_ntotal(const ssmi_index* h, int64_t* out);
+int ssmi_index_get_is_trained(const ssmi_index* h, int* out);
+int ssmi_index_get_nlist(const ssmi_index* h, int* out);
+int ssmi_index_get_nprobe(const ssmi_index* h, int* out);
+int ssmi_index_set_nprobe(ssmi_index* h, int nprobe);
+int ssmi_index_get_storage_dtype(const ssmi_index* h, int* out);
+int ssmi_index_get_device(const ssmi_index* h, int* out);
+
+/* ---- train / add -------------------------------------------------------- */
+/* replaces index.train(x)                          core/index_factory.py:191
+ * x: (n,d) fp32 row-major.  Flat: no-op.  IVF: k-means of nlist centroids. */
+int ssmi_index_train(ssmi_index* h, int64_t n, const float* x, int mem_kind);
+/* IVF only: install given centroids (nlist,d) fp32 instead of running k-means
+ * (no reference counterpart: used by parity tests and by ssmi_index_read). */
+int ssmi_index_set_centroids(ssmi_index* h, const float* centroids, int mem_kind);
+int ssmi_index_get_centroids(const ssmi_index* h, float* out_host);
+/* replaces index.add(x)     core/index_manager.py:299,308,319,1188;
+ *                           core/index_factory.py:307,411
+ * x: (n,d) row-major of src_dtype, host or device. */
+int ssmi_index_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind);
+/* bench/test helper (no reference counterpart): append n rows of i.i.d.
+ * N(0,1) components, L2-normalised per row, generated on the device. */
+int ssmi_index_add_random_unit(ssmi_index* h, int64_t n, uint64_t seed);
+
+/* ---- search ------------------------------------------------------------- */
+/* replaces index.search(x, k)                      core/index_manager.py:371
+ * q: (nq,d) fp32 row-major (host or device per q_mem_kind).
+ * D: (nq,k) fp32, I: (nq,k) int64, row-major, host or device per out_mem_kind.
+ * id_offset is added to every valid id (row-sharded databases).
+ * stream: the hipStream_t the work is enqueued on.  When q and D/I are all host
+ * buffers NULL selects the handle's own stream; when either lives on the device
+ * the given stream is used as is (NULL = the HIP null stream).  With host
+ * outputs the call returns after the results are in D/I; with device outputs
+ * it returns after enqueueing on `stream` (caller synchronises). */
+int ssmi_index_search(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind,
+                      int k, float* D, int64_t* I, int out_mem_kind,
+                      int64_t id_offset, void* stream);
+
+/* merge step of a sharded search (the RCCL all-gather's consumer; no reference
+ * counterpart - the reference is single-index).  Inputs are `nlists` result
+ * sets laid out [nlists][nq][k] on the device (what all_gather produces);
+ * output is the (nq,k) top-k of their union, same ordering rules. */
+int ssmi_topk_merge(int device, int nlists, int64_t nq, int k,
+                    const float* D_lists, const int64_t* I_lists,
+                    float* D_out, int64_t* I_out, void* stream);
+
+/* ---- read back ---------------------------------------------------------- */
+/* replaces index.reconstruct(i)   core/index_factory.py:274,372;
+ *                                 core/index_manager.py:609    (bulk form)
+ * out: (n,d) fp32 host.  IVF handles need ssmi_index_make_direct_map first,
+ * otherwise this fails like FAISS does without a direct map. */
+int ssmi_index_reconstruct_n(ssmi_index* h, int64_t n, const int64_t* ids, float* out_host);
+int ssmi_index_make_direct_map(ssmi_index* h);
+
+/* ---- persistence -------------------------------------------------------- */
+/* replaces faiss.write_index(index, path)          core/index_manager.py:241 */
+int ssmi_index_write(ssmi_index* h, const char* path);
+/* replaces faiss.read_index(path)                  core/index_manager.py:185 */
+int ssmi_index_read(const char* path, int storage_dtype, int device, ssmi_index** out);
+
+/* ---- introspection ------------------------------------------------------ */
+typedef struct ssmi_timing {
+    double last_search_ms;   /* hipEvent time of the last search's kernels */
+    double last_scan_ms;     /* ... of its dominant (scan / contraction) kernel */
+    double last_merge_ms;
+    int64_t last_scan_bytes; /* algorithmic bytes the dominant kernel streamed */
+    int64_t last_scan_flops;
+    int last_path;           /* 0 = streaming scan, 1 = MFMA contraction, 2 = IVF */
+    int last_grid;
+} ssmi_timing;
+int ssmi_index_get_timing(const ssmi_index* h, ssmi_timing* out);
+/* hipEvent durations (ms) of the dominant kernel (scan / contraction) of the last
+ * min(max_n, 256) searches on this handle, oldest first (bench.py's roofline leg). */
+int ssmi_index_get_scan_times(const ssmi_index* h, int max_n, float* ms_out, int* n_out);
+/* IVF introspection for tests: list sizes (nlist int64) */
+int ssmi_index_get_list_sizes(const ssmi_index* h, int64_t* out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSMI_H */

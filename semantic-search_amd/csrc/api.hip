@@ -1,0 +1,510 @@
+// api.hip - the C-ABI of libssmi.so (include/ssmi.h) and the host-side index
+// objects behind it.  Host logic only; kernels are in scan_*/merge/util/...
+#include "../../include/ssmi.h"
+#include "kernels.h"
+#include "index.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <algorithm>
+
+using namespace ssmi;
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+namespace ssmi {
+int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+}  // namespace ssmi
+
+#define HIPCHECK(expr)                                                                             \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+#define CHECK(expr)        \
+    do {                   \
+        int rc__ = (expr); \
+        if (rc__) return rc__; \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// RowStore
+// ---------------------------------------------------------------------------
+namespace ssmi {
+
+int RowStore::init(int d_, int dtype_) {
+    d = d_;
+    dtype = dtype_;
+    elsize = dtype == SSMI_F32 ? 4 : 2;
+    ld = (d + 7) / 8 * 8;
+    row_bytes = (size_t)ld * elsize;
+    // ~1 GiB segments, between 2^10 and 2^24 rows
+    seg_shift = 10;
+    while (seg_shift < 24 && (row_bytes << (seg_shift + 1)) <= ((size_t)1 << 30)) ++seg_shift;
+    const char* env = getenv("SSMI_SEG_SHIFT");  // tests use small segments to exercise the table
+    if (env) { int v = atoi(env); if (v >= 4 && v <= 24) seg_shift = v; }
+    nrows = 0;
+    seg0_cap = 0;
+    HIPCHECK(hipMalloc((void**)&d_segs, sizeof(void*) * kMaxSegs));
+    HIPCHECK(hipMemset(d_segs, 0, sizeof(void*) * kMaxSegs));
+    return 0;
+}
+
+void RowStore::destroy() {
+    for (void* p : segs) if (p) (void)hipFree(p);
+    segs.clear();
+    if (d_segs) (void)hipFree(d_segs);
+    d_segs = nullptr;
+    nrows = 0;
+    seg0_cap = 0;
+}
+
+int RowStore::reserve(long long total, hipStream_t stream) {
+    const long long seg_rows = 1ll << seg_shift;
+    if (total <= 0) return 0;
+    const long long nseg_needed = (total + seg_rows - 1) / seg_rows;
+    if (nseg_needed > kMaxSegs) return fail("index too large: %lld rows exceed %d segments", total, kMaxSegs);
+    bool table_dirty = false;
+    // segment 0 grows by doubling until it reaches the full segment size
+    long long want0 = std::min(total, seg_rows);
+    if (want0 > seg0_cap) {
+        long long cap = seg0_cap > 0 ? seg0_cap : 256;
+        while (cap < want0) cap <<= 1;
+        if (cap > seg_rows) cap = seg_rows;
+        void* p = nullptr;
+        HIPCHECK(hipMalloc(&p, (size_t)cap * row_bytes));
+        if (!segs.empty() && segs[0]) {
+            const long long live = std::min(nrows, seg0_cap);
+            if (live > 0) HIPCHECK(hipMemcpyAsync(p, segs[0], (size_t)live * row_bytes, hipMemcpyDeviceToDevice, stream));
+            HIPCHECK(hipStreamSynchronize(stream));
+            HIPCHECK(hipFree(segs[0]));
+            segs[0] = p;
+        } else if (segs.empty()) {
+            segs.push_back(p);
+        } else {
+            segs[0] = p;
+        }
+        seg0_cap = cap;
+        table_dirty = true;
+    }
+    while ((long long)segs.size() < nseg_needed) {
+        void* p = nullptr;
+        HIPCHECK(hipMalloc(&p, (size_t)seg_rows * row_bytes));
+        segs.push_back(p);
+        table_dirty = true;
+    }
+    if (table_dirty) {
+        HIPCHECK(hipMemcpyAsync(d_segs, segs.data(), sizeof(void*) * segs.size(), hipMemcpyHostToDevice, stream));
+        HIPCHECK(hipStreamSynchronize(stream));
+    }
+    return 0;
+}
+
+RowView RowStore::view() const {
+    RowView v;
+    v.segs = (const void* const*)d_segs;
+    v.seg_shift = seg_shift;
+    v.ld = ld;
+    v.nrows = nrows;
+    return v;
+}
+
+}  // namespace ssmi
+
+// ---------------------------------------------------------------------------
+// index object helpers
+// ---------------------------------------------------------------------------
+namespace ssmi {
+int ensure_ws(ssmi_index* h, int slot, size_t bytes) {
+    if (h->ws_bytes[slot] >= bytes && h->ws[slot]) return 0;
+    // a caller-provided stream may still be using the old buffer: drain the device (rare path)
+    if (h->ws[slot]) { HIPCHECK(hipDeviceSynchronize()); HIPCHECK(hipFree(h->ws[slot])); h->ws[slot] = nullptr; h->ws_bytes[slot] = 0; }
+    size_t cap = std::max(bytes, (size_t)1 << 20);
+    cap = (cap + 255) / 256 * 256;
+    HIPCHECK(hipMalloc(&h->ws[slot], cap));
+    h->ws_bytes[slot] = cap;
+    return 0;
+}
+}  // namespace ssmi
+
+static int create_common(int d, int storage_dtype, int device, int kind, ssmi_index** out) {
+    if (!out) return fail("out is NULL");
+    *out = nullptr;
+    if (d < 1 || d > 65536) return fail("dimension %d out of range [1, 65536]", d);
+    if (storage_dtype != SSMI_F32 && storage_dtype != SSMI_F16) return fail("unknown storage dtype %d", storage_dtype);
+    int ndev = 0;
+    HIPCHECK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("device %d not available (%d visible)", device, ndev);
+    DeviceGuard g(device);
+    if (!g.ok) return fail("hipSetDevice(%d) failed", device);
+    ssmi_index* h = new ssmi_index();
+    h->kind = kind;
+    h->device = device;
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, device));
+    h->num_cu = prop.multiProcessorCount;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        delete h;
+        return fail("libssmi is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+    }
+    HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (int i = 0; i < ssmi_index::kEvRing; ++i)
+        for (int j = 0; j < 3; ++j) HIPCHECK(hipEventCreate(&h->ev[i][j]));
+    if (h->rows.init(d, storage_dtype)) { delete h; return 1; }
+    *out = h;
+    return 0;
+}
+
+// Pads/stages queries on the device; returns the (nq, ld) fp32 device pointer.
+namespace ssmi {
+int stage_queries(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind, hipStream_t s, const float** out) {
+    const RowStore& R = h->rows;
+    if (q_mem_kind == SSMI_DEVICE && R.ld == R.d) { *out = q; return 0; }
+    CHECK(ensure_ws(h, 1, (size_t)nq * R.ld * 4));
+    float* qp = (float*)h->ws[1];
+    if (q_mem_kind == SSMI_HOST) {
+        if (R.ld == R.d) {
+            HIPCHECK(hipMemcpyAsync(qp, q, (size_t)nq * R.d * 4, hipMemcpyHostToDevice, s));
+        } else {
+            HIPCHECK(hipMemsetAsync(qp, 0, (size_t)nq * R.ld * 4, s));
+            HIPCHECK(hipMemcpy2DAsync(qp, (size_t)R.ld * 4, q, (size_t)R.d * 4, (size_t)R.d * 4, (size_t)nq,
+                                      hipMemcpyHostToDevice, s));
+        }
+    } else {
+        HIPCHECK(launch_pad_queries(q, (int)nq, R.d, R.ld, qp, s));
+    }
+    *out = qp;
+    return 0;
+}
+}  // namespace ssmi
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char* ssmi_last_error(void) { return g_err.c_str(); }
+int ssmi_abi_version(void) { return 1; }
+int ssmi_device_count(int* out) {
+    if (!out) return fail("out is NULL");
+    HIPCHECK(hipGetDeviceCount(out));
+    return 0;
+}
+
+int ssmi_index_create_flat(int d, int storage_dtype, int device, ssmi_index** out) {
+    return create_common(d, storage_dtype, device, SSMI_KIND_FLAT, out);
+}
+
+int ssmi_index_free(ssmi_index* h) {
+    if (!h) return 0;
+    DeviceGuard g(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    ivf_destroy(h);
+    h->rows.destroy();
+    for (int i = 0; i < kWsSlots; ++i) if (h->ws[i]) (void)hipFree(h->ws[i]);
+    for (int i = 0; i < ssmi_index::kEvRing; ++i)
+        for (int j = 0; j < 3; ++j) if (h->ev[i][j]) (void)hipEventDestroy(h->ev[i][j]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+#define GETTER(name, type, expr)                              \
+    int ssmi_index_get_##name(const ssmi_index* h, type* out) { \
+        if (!h || !out) return fail("NULL argument");         \
+        *out = (expr);                                        \
+        return 0;                                             \
+    }
+GETTER(kind, int, h->kind)
+GETTER(d, int, h->rows.d)
+GETTER(ntotal, int64_t, h->kind == SSMI_KIND_FLAT ? h->rows.nrows : h->ivf_ntotal)
+GETTER(is_trained, int, h->kind == SSMI_KIND_FLAT ? 1 : (h->trained ? 1 : 0))
+GETTER(storage_dtype, int, h->rows.dtype)
+GETTER(device, int, h->device)
+
+int ssmi_index_get_nlist(const ssmi_index* h, int* out) {
+    if (!h || !out) return fail("NULL argument");
+    if (h->kind != SSMI_KIND_IVFFLAT) return fail("nlist: not an IVF index");
+    *out = h->nlist;
+    return 0;
+}
+int ssmi_index_get_nprobe(const ssmi_index* h, int* out) {
+    if (!h || !out) return fail("NULL argument");
+    if (h->kind != SSMI_KIND_IVFFLAT) return fail("nprobe: not an IVF index");
+    *out = h->nprobe;
+    return 0;
+}
+int ssmi_index_set_nprobe(ssmi_index* h, int nprobe) {
+    if (!h) return fail("NULL argument");
+    if (h->kind != SSMI_KIND_IVFFLAT) return fail("nprobe: not an IVF index");
+    if (nprobe < 1) return fail("nprobe must be >= 1");
+    h->nprobe = nprobe;
+    return 0;
+}
+
+// --------------------------------------------------------------------- add
+static int flat_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind) {
+    RowStore& R = h->rows;
+    const long long row0 = R.nrows;
+    if ((unsigned long long)(row0 + n) >= 0xFFFFFFFFull) return fail("index would exceed 2^32-2 vectors");
+    CHECK(R.reserve(row0 + n, h->stream));
+    const size_t src_el = src_dtype == SSMI_F32 ? 4 : 2;
+    const long long seg_rows = 1ll << R.seg_shift;
+    if (src_dtype == R.dtype && R.ld == R.d) {
+        // rows are bit-identical to the source: plain copies, one per segment touched
+        long long done = 0;
+        while (done < n) {
+            const long long row = row0 + done;
+            const long long seg = row >> R.seg_shift, off = row & (seg_rows - 1);
+            const long long cnt = std::min<long long>(n - done, seg_rows - off);
+            HIPCHECK(hipMemcpyAsync((char*)R.segs[seg] + (size_t)off * R.row_bytes,
+                                    (const char*)x + (size_t)done * R.row_bytes, (size_t)cnt * R.row_bytes,
+                                    mem_kind == SSMI_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->stream));
+            done += cnt;
+        }
+    } else {
+        RowView v = R.view();
+        const long long chunk = std::max<long long>(1, ((size_t)64 << 20) / ((size_t)R.d * src_el));
+        long long done = 0;
+        while (done < n) {
+            const long long cnt = std::min<long long>(chunk, n - done);
+            const void* src = (const char*)x + (size_t)done * R.d * src_el;
+            if (mem_kind == SSMI_HOST) {
+                CHECK(ensure_ws(h, 0, (size_t)cnt * R.d * src_el));
+                HIPCHECK(hipMemcpyAsync(h->ws[0], src, (size_t)cnt * R.d * src_el, hipMemcpyHostToDevice, h->stream));
+                src = h->ws[0];
+            }
+            HIPCHECK(launch_cvt_store(src, src_dtype, cnt, R.d, v, R.dtype, (void* const*)R.d_segs, row0 + done, h->stream));
+            if (mem_kind == SSMI_HOST) HIPCHECK(hipStreamSynchronize(h->stream));  // staging buffer reused
+            done += cnt;
+        }
+    }
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    R.nrows = row0 + n;
+    return 0;
+}
+
+int ssmi_index_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind) {
+    if (!h) return fail("NULL index");
+    if (n < 0) return fail("negative n");
+    if (n == 0) return 0;
+    if (!x) return fail("NULL vectors");
+    if (src_dtype != SSMI_F32 && src_dtype != SSMI_F16) return fail("unknown source dtype %d", src_dtype);
+    if (mem_kind != SSMI_HOST && mem_kind != SSMI_DEVICE) return fail("unknown mem_kind %d", mem_kind);
+    DeviceGuard g(h->device);
+    if (h->kind == SSMI_KIND_FLAT) return flat_add(h, n, x, src_dtype, mem_kind);
+    return ivf_add(h, n, x, src_dtype, mem_kind);
+}
+
+int ssmi_index_add_random_unit(ssmi_index* h, int64_t n, uint64_t seed) {
+    if (!h) return fail("NULL index");
+    if (n < 0) return fail("negative n");
+    if (n == 0) return 0;
+    DeviceGuard g(h->device);
+    if (h->kind != SSMI_KIND_FLAT) return ivf_add_random_unit(h, n, seed);
+    RowStore& R = h->rows;
+    const long long row0 = R.nrows;
+    if ((unsigned long long)(row0 + n) >= 0xFFFFFFFFull) return fail("index would exceed 2^32-2 vectors");
+    CHECK(R.reserve(row0 + n, h->stream));
+    HIPCHECK(launch_fill_random_unit(R.view(), R.dtype, (void* const*)R.d_segs, row0, n, R.d, seed, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    R.nrows = row0 + n;
+    return 0;
+}
+
+int ssmi_index_train(ssmi_index* h, int64_t n, const float* x, int mem_kind) {
+    if (!h) return fail("NULL index");
+    if (h->kind == SSMI_KIND_FLAT) return 0;  // IndexFlatIP.train is a no-op
+    DeviceGuard g(h->device);
+    return ivf_train(h, n, x, mem_kind);
+}
+
+// ------------------------------------------------------------------ search
+static int flat_search(ssmi_index* h, int64_t nq, const float* qdev /*(nq,ld)*/, int k, float* Ddev, int64_t* Idev,
+                       int64_t id_offset, hipStream_t s) {
+    const RowStore& R = h->rows;
+    ScanPlan p;
+    std::string err;
+    // bound the partial-list buffer: process queries in batches
+    int64_t done = 0;
+    bool first = true;
+    hipEvent_t* ev = h->ev[h->n_searches % ssmi_index::kEvRing];
+    while (done < nq) {
+        int64_t nb = nq - done;
+        if (!plan_flat_scan(R.dtype, R.ld, R.nrows, (int)std::min<int64_t>(nb, 1 << 20), k, h->num_cu, &p, &err))
+            return fail("%s", err.c_str());
+        const size_t per_q = (size_t)p.grid_x * k * sizeof(skey_t);
+        const int64_t cap = std::max<int64_t>(p.bt, (int64_t)(((size_t)256 << 20) / per_q) / p.bt * p.bt);
+        if (nb > cap) nb = cap;
+        p.grid_y = (int)((nb + p.bt - 1) / p.bt);
+        CHECK(ensure_ws(h, 2, (size_t)nb * per_q));
+        skey_t* partial = (skey_t*)h->ws[2];
+        const float* qb = qdev + (size_t)done * R.ld;
+        if (first) HIPCHECK(hipEventRecord(ev[0], s));
+        if (R.dtype == SSMI_F32) HIPCHECK(launch_flat_scan_f32(R.view(), qb, (int)nb, k, partial, p, s));
+        else HIPCHECK(launch_flat_scan_f16(R.view(), qb, (int)nb, k, partial, p, s));
+        if (first) HIPCHECK(hipEventRecord(ev[1], s));
+        HIPCHECK(launch_merge_keys(partial, (int)nb, p.grid_x, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
+                                   id_offset, s));
+        if (first) HIPCHECK(hipEventRecord(ev[2], s));
+        first = false;
+        done += nb;
+    }
+    h->n_searches++;
+    h->timing_valid = true;
+    h->timing.last_path = 0;
+    h->timing.last_grid = p.grid_x * p.grid_y;
+    h->timing.last_scan_bytes = (int64_t)R.nrows * R.d * R.elsize * ((nq + p.bt - 1) / p.bt);
+    h->timing.last_scan_flops = 2ll * nq * R.nrows * R.d;
+    return 0;
+}
+
+int ssmi_index_search(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind, int k, float* D, int64_t* I,
+                      int out_mem_kind, int64_t id_offset, void* stream) {
+    if (!h) return fail("NULL index");
+    if (nq < 0) return fail("negative nq");
+    if (nq == 0) return 0;
+    if (!q || !D || !I) return fail("NULL buffer");
+    if (k < 1) return fail("k must be >= 1");
+    if (k > kMaxK) return fail("k=%d exceeds the supported maximum %d", k, kMaxK);
+    if (nq > (1ll << 24)) return fail("nq too large");
+    if (q_mem_kind != SSMI_HOST && q_mem_kind != SSMI_DEVICE) return fail("unknown q_mem_kind %d", q_mem_kind);
+    if (out_mem_kind != SSMI_HOST && out_mem_kind != SSMI_DEVICE) return fail("unknown out_mem_kind %d", out_mem_kind);
+    DeviceGuard g(h->device);
+    // all-host call with no stream: the handle's own stream; otherwise exactly the caller's
+    // stream (NULL then means the HIP null stream, e.g. torch's default stream)
+    const bool any_dev = q_mem_kind == SSMI_DEVICE || out_mem_kind == SSMI_DEVICE;
+    hipStream_t s = (stream || any_dev) ? (hipStream_t)stream : h->stream;
+    if (h->kind == SSMI_KIND_IVFFLAT && !h->trained) return fail("search on an untrained IVF index");
+
+    float* Ddev = D;
+    int64_t* Idev = I;
+    if (out_mem_kind == SSMI_HOST) {
+        const size_t d_bytes = ((size_t)nq * k * 4 + 255) / 256 * 256;
+        CHECK(ensure_ws(h, 3, d_bytes + (size_t)nq * k * 8));
+        Ddev = (float*)h->ws[3];
+        Idev = (int64_t*)((char*)h->ws[3] + d_bytes);
+    }
+    const int64_t ntotal = h->kind == SSMI_KIND_FLAT ? h->rows.nrows : h->ivf_ntotal;
+    if (ntotal == 0) {
+        HIPCHECK(launch_fill_empty(Ddev, Idev, nq * k, s));
+    } else {
+        const float* qdev = nullptr;
+        CHECK(stage_queries(h, nq, q, q_mem_kind, s, &qdev));
+        if (h->kind == SSMI_KIND_FLAT) CHECK(flat_search(h, nq, qdev, k, Ddev, Idev, id_offset, s));
+        else CHECK(ivf_search(h, nq, qdev, k, Ddev, Idev, id_offset, s));
+    }
+    if (out_mem_kind == SSMI_HOST) {
+        HIPCHECK(hipMemcpyAsync(D, Ddev, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipMemcpyAsync(I, Idev, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+int ssmi_topk_merge(int device, int nlists, int64_t nq, int k, const float* D_lists, const int64_t* I_lists,
+                    float* D_out, int64_t* I_out, void* stream) {
+    if (nlists < 1 || nq < 0 || k < 1) return fail("bad merge shape");
+    if (k > kMaxK) return fail("k=%d exceeds the supported maximum %d", k, kMaxK);
+    if (nq == 0) return 0;
+    if (!D_lists || !I_lists || !D_out || !I_out) return fail("NULL buffer");
+    DeviceGuard g(device);
+    if (!g.ok) return fail("hipSetDevice(%d) failed", device);
+    HIPCHECK(launch_merge_lists(D_lists, I_lists, nlists, (int)nq, k, D_out, I_out, (hipStream_t)stream));
+    return 0;
+}
+
+// ------------------------------------------------------------- reconstruct
+int ssmi_index_reconstruct_n(ssmi_index* h, int64_t n, const int64_t* ids, float* out_host) {
+    if (!h) return fail("NULL index");
+    if (n < 0) return fail("negative n");
+    if (n == 0) return 0;
+    if (!ids || !out_host) return fail("NULL buffer");
+    DeviceGuard g(h->device);
+    const RowStore& R = h->rows;
+    const int64_t ntotal = h->kind == SSMI_KIND_FLAT ? R.nrows : h->ivf_ntotal;
+    for (int64_t i = 0; i < n; ++i)
+        if (ids[i] < 0 || ids[i] >= ntotal) return fail("reconstruct: id %lld out of range [0, %lld)", (long long)ids[i], (long long)ntotal);
+    std::vector<int64_t> slots;
+    const int64_t* src_ids = ids;
+    if (h->kind == SSMI_KIND_IVFFLAT) {
+        CHECK(ivf_ids_to_slots(h, n, ids, &slots));
+        src_ids = slots.data();
+    }
+    const int64_t chunk = std::max<int64_t>(1, ((size_t)64 << 20) / ((size_t)R.d * 4));
+    for (int64_t done = 0; done < n; done += chunk) {
+        const int64_t cnt = std::min(chunk, n - done);
+        const size_t ids_bytes = ((size_t)cnt * 8 + 255) / 256 * 256;
+        CHECK(ensure_ws(h, 0, ids_bytes + 256 + (size_t)cnt * R.d * 4));
+        int64_t* dids = (int64_t*)h->ws[0];
+        int* bad = (int*)((char*)h->ws[0] + ids_bytes);
+        float* dout = (float*)((char*)h->ws[0] + ids_bytes + 256);
+        HIPCHECK(hipMemcpyAsync(dids, src_ids + done, (size_t)cnt * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(hipMemsetAsync(bad, 0, 4, h->stream));
+        RowView v = R.view();
+        if (h->kind == SSMI_KIND_IVFFLAT) v.nrows = h->ivf_slots_used;
+        HIPCHECK(launch_gather_rows(v, R.dtype, dids, cnt, R.d, dout, bad, h->stream));
+        HIPCHECK(hipMemcpyAsync(out_host + (size_t)done * R.d, dout, (size_t)cnt * R.d * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+// ----------------------------------------------------------------- timing
+int ssmi_index_get_timing(const ssmi_index* h, ssmi_timing* out) {
+    if (!h || !out) return fail("NULL argument");
+    if (!h->timing_valid) return fail("no search has run on this index");
+    DeviceGuard g(h->device);
+    ssmi_timing t = h->timing;
+    hipEvent_t const* ev = h->ev[(h->n_searches - 1) % ssmi_index::kEvRing];
+    HIPCHECK(hipEventSynchronize(ev[2]));
+    float a = 0, b = 0;
+    HIPCHECK(hipEventElapsedTime(&a, ev[0], ev[1]));
+    HIPCHECK(hipEventElapsedTime(&b, ev[1], ev[2]));
+    t.last_scan_ms = a;
+    t.last_merge_ms = b;
+    t.last_search_ms = a + b;
+    *out = t;
+    return 0;
+}
+
+// durations (ms) of the dominant kernel of the last `max_n` searches, oldest first
+int ssmi_index_get_scan_times(const ssmi_index* h, int max_n, float* ms_out, int* n_out) {
+    if (!h || !ms_out || !n_out) return fail("NULL argument");
+    DeviceGuard g(h->device);
+    long long n = std::min<long long>(std::min<long long>(max_n, h->n_searches), ssmi_index::kEvRing);
+    for (long long i = 0; i < n; ++i) {
+        hipEvent_t const* ev = h->ev[(h->n_searches - n + i) % ssmi_index::kEvRing];
+        HIPCHECK(hipEventSynchronize(ev[1]));
+        HIPCHECK(hipEventElapsedTime(&ms_out[i], ev[0], ev[1]));
+    }
+    *n_out = (int)n;
+    return 0;
+}
+
+}  // extern "C"

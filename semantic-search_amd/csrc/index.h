@@ -1,0 +1,72 @@
+// index.h - host-side index objects behind the opaque ssmi_index handle.
+#pragma once
+#include "../../include/ssmi.h"
+#include "common.h"
+#include <vector>
+#include <string>
+
+namespace ssmi {
+
+static const int kMaxSegs = 4096;
+static const int kWsSlots = 8;
+
+int fail(const char* fmt, ...);
+
+// Device row store: equally sized segments (~1 GiB) addressed through a device
+// pointer table, so an index grows without ever copying more than segment 0.
+// Rows are padded to a multiple of 8 elements with zeros (16-byte row alignment).
+struct RowStore {
+    int d = 0, ld = 0, dtype = 0, seg_shift = 0;
+    size_t elsize = 0, row_bytes = 0;
+    long long nrows = 0;
+    long long seg0_cap = 0;  // rows allocated in segment 0 (grows by doubling)
+    std::vector<void*> segs;
+    void** d_segs = nullptr;
+
+    int init(int d, int dtype);
+    void destroy();
+    int reserve(long long total_rows, hipStream_t stream);
+    RowView view() const;
+};
+
+}  // namespace ssmi
+
+struct ssmi_index {
+    int kind = 0;
+    int device = 0;
+    int num_cu = 256;
+    ssmi::RowStore rows;  // Flat: the database.  IVF: the slot store (pages of list members)
+    hipStream_t stream = nullptr;
+    // ring of (scan start, scan stop, merge stop) event triples, one per search call
+    static const int kEvRing = 256;
+    hipEvent_t ev[kEvRing][3] = {};
+    long long n_searches = 0;
+    void* ws[ssmi::kWsSlots] = {};
+    size_t ws_bytes[ssmi::kWsSlots] = {};
+    ssmi_timing timing = {};
+    bool timing_valid = false;
+
+    // ---- IVF state (kind == SSMI_KIND_IVFFLAT) ----
+    int nlist = 0, nprobe = 1;
+    bool trained = false;
+    long long ivf_ntotal = 0;
+    long long ivf_slots_used = 0;  // slots handed out in `rows` (pages * page_rows)
+    void* ivf = nullptr;           // ssmi::IvfState*
+};
+
+namespace ssmi {
+// grow-only device workspace slots (0: staging, 1: queries, 2: partial lists, 3: host-output staging, 4+: IVF)
+int ensure_ws(ssmi_index* h, int slot, size_t bytes);
+// query staging shared by the flat and IVF paths: returns (nq, ld) fp32 on device
+int stage_queries(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind, hipStream_t s, const float** out);
+
+// IVF entry points (ivf.hip)
+int ivf_create(ssmi_index* h, int nlist);
+void ivf_destroy(ssmi_index* h);
+int ivf_train(ssmi_index* h, int64_t n, const float* x, int mem_kind);
+int ivf_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind);
+int ivf_add_random_unit(ssmi_index* h, int64_t n, uint64_t seed);
+int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev, int64_t* Idev, int64_t id_offset,
+               hipStream_t s);
+int ivf_ids_to_slots(ssmi_index* h, int64_t n, const int64_t* ids, std::vector<int64_t>* slots);
+}  // namespace ssmi

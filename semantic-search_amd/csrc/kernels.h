@@ -1,0 +1,45 @@
+// kernels.h - host-callable launchers of the HIP kernels (internal to libssmi).
+#pragma once
+#include "common.h"
+
+namespace ssmi {
+
+struct ScanPlan {
+    int bt;        // queries per block pass
+    int r;         // per-wave list length / 64
+    int nch;       // static chunks per row (0 = runtime loop)
+    bool qreg;     // query in registers
+    bool nt;       // non-temporal row loads
+    int threads;
+    int grid_x;    // row slices == partial lists per query
+    int grid_y;    // query tiles
+    size_t lds;    // dynamic LDS bytes
+};
+
+// K1 planning + launch
+bool plan_flat_scan(int dtype, int ld, long long nrows, int nq, int k, int num_cu, ScanPlan* p, std::string* err);
+hipError_t launch_flat_scan_f32(const RowView& X, const float* Q, int nq, int k, skey_t* partial, const ScanPlan& p, hipStream_t s);
+hipError_t launch_flat_scan_f16(const RowView& X, const float* Q, int nq, int k, skey_t* partial, const ScanPlan& p, hipStream_t s);
+
+// K3: merge P sorted k-lists of keys per query -> (D, I)
+hipError_t launch_merge_keys(const skey_t* partial, int nq, int P, int k, float* D, int64_t* I,
+                             int64_t id_offset, hipStream_t s);
+// K3': merge `nlists` (D,I) result sets [nlists][nq][k] -> (D, I)
+hipError_t launch_merge_lists(const float* Dl, const int64_t* Il, int nlists, int nq, int k, float* D,
+                              int64_t* I, hipStream_t s);
+
+// K4: rows (n,d) of src dtype -> storage rows [row0, row0+n) with zero padding to ld
+hipError_t launch_cvt_store(const void* src, int src_dtype, long long n, int d, const RowView& X, int dst_dtype,
+                            void* const* segs_rw, long long row0, hipStream_t s);
+// K9: gather rows by id -> fp32 (n,d); ids out of range produce NaN-free zeros and set *bad
+hipError_t launch_gather_rows(const RowView& X, int dtype, const int64_t* ids, long long n, int d, float* out,
+                              int* bad, hipStream_t s);
+// K10: append unit-norm gaussian rows [row0,row0+n)
+hipError_t launch_fill_random_unit(const RowView& X, int dtype, void* const* segs_rw, long long row0, long long n,
+                                   int d, uint64_t seed, hipStream_t s);
+// fill (nq,k) outputs with the "no result" padding
+hipError_t launch_fill_empty(float* D, int64_t* I, long long n, hipStream_t s);
+// pad queries (nq,d) -> (nq,ld) fp32 (zero tail)
+hipError_t launch_pad_queries(const float* q, int nq, int d, int ld, float* out, hipStream_t s);
+
+}  // namespace ssmi

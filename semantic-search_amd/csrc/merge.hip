@@ -1,0 +1,121 @@
+// merge.hip - K3: merge sorted per-block (or per-shard) top-k lists into the
+// final (D, I) of a search.  One workgroup per query; each wave folds a strided
+// subset of the lists into its register list with bitonic merges (topk.h), the
+// waves combine through LDS, wave 0 decodes keys to (score, id).
+//
+// Stands in for the heap bookkeeping inside faiss.IndexFlatIP.search
+// (reference call site core/index_manager.py:371) and, in the sharded form, for
+// the result merge the north-star asks for after the RCCL all-gather.
+#include "kernels.h"
+#include "topk.h"
+#include <type_traits>
+
+namespace ssmi {
+
+template <int R>
+__device__ __forceinline__ void write_result(const WaveTopK<R>& t, int k, float* D, int64_t* I, int64_t id_offset) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int e = r * 64 + lane;
+        if (e < k) {
+            const skey_t key = t.v[r];
+            if (key == 0) { D[e] = SSMI_NEG_MAX; I[e] = -1; }
+            else { D[e] = key_score(key); I[e] = (int64_t)key_id(key) + id_offset; }
+        }
+    }
+}
+
+template <int R>
+__global__ void merge_keys_kernel(const skey_t* __restrict__ partial, int P, int k, float* __restrict__ D,
+                                  int64_t* __restrict__ I, int64_t id_offset) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    skey_t* lds = reinterpret_cast<skey_t*>(smem);
+    const int q = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = (int)(blockDim.x >> 6);
+    WaveTopK<R> t;
+    t.init();
+    for (int p = wave; p < P; p += nwaves) t.merge_from(partial + ((size_t)q * P + p) * k, k);
+    block_merge<R>(t, lds, wave, nwaves);
+    if (wave == 0) write_result<R>(t, k, D + (size_t)q * k, I + (size_t)q * k, id_offset);
+}
+
+// lists given as (D, I) pairs laid out [nlists][nq][k]
+template <int R>
+__global__ void merge_lists_kernel(const float* __restrict__ Dl, const int64_t* __restrict__ Il, int nlists, int nq,
+                                   int k, float* __restrict__ D, int64_t* __restrict__ I) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    skey_t* lds = reinterpret_cast<skey_t*>(smem);
+    const int KP = WaveTopK<R>::KP;
+    const int q = blockIdx.x;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = (int)(blockDim.x >> 6);
+    // stage this wave's current list as keys in its LDS slot, then merge from there
+    skey_t* slot = lds + (size_t)wave * KP;
+    WaveTopK<R> t;
+    t.init();
+    for (int p = wave; p < nlists; p += nwaves) {
+        const size_t base = ((size_t)p * nq + q) * k;
+        for (int e = lane; e < k; e += 64) {
+            const int64_t id = Il[base + e];
+            slot[e] = (id < 0) ? 0 : make_key(Dl[base + e], (uint32_t)id);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave visible to itself
+        __builtin_amdgcn_wave_barrier();
+        t.merge_from(slot, k);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    block_merge<R>(t, lds, wave, nwaves);
+    if (wave == 0) write_result<R>(t, k, D + (size_t)q * k, I + (size_t)q * k, 0);
+}
+
+static int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+template <typename F>
+static hipError_t dispatch_r(int r, F f) {
+    switch (r) {
+        case 1: return f(std::integral_constant<int, 1>());
+        case 2: return f(std::integral_constant<int, 2>());
+        case 4: return f(std::integral_constant<int, 4>());
+        case 8: return f(std::integral_constant<int, 8>());
+        case 16: return f(std::integral_constant<int, 16>());
+    }
+    return hipErrorInvalidValue;
+}
+
+static int merge_waves(int P, int kp) {
+    int w = P < 16 ? (P < 1 ? 1 : P) : 16;
+    while (w > 1 && (size_t)w * kp * sizeof(skey_t) > 64 * 1024) --w;
+    return w;
+}
+
+hipError_t launch_merge_keys(const skey_t* partial, int nq, int P, int k, float* D, int64_t* I, int64_t id_offset,
+                             hipStream_t s) {
+    if (nq <= 0) return hipSuccess;
+    const int r = pow2_ceil((k + 63) / 64);
+    const int w = merge_waves(P, 64 * r);
+    const size_t lds = (size_t)w * 64 * r * sizeof(skey_t);
+    return dispatch_r(r, [&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        hipLaunchKernelGGL((merge_keys_kernel<R>), dim3(nq), dim3(64 * w), lds, s, partial, P, k, D, I, id_offset);
+        return hipGetLastError();
+    });
+}
+
+hipError_t launch_merge_lists(const float* Dl, const int64_t* Il, int nlists, int nq, int k, float* D, int64_t* I,
+                              hipStream_t s) {
+    if (nq <= 0) return hipSuccess;
+    const int r = pow2_ceil((k + 63) / 64);
+    const int w = merge_waves(nlists, 64 * r);
+    const size_t lds = (size_t)w * 64 * r * sizeof(skey_t);
+    return dispatch_r(r, [&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        hipLaunchKernelGGL((merge_lists_kernel<R>), dim3(nq), dim3(64 * w), lds, s, Dl, Il, nlists, nq, k, D, I);
+        return hipGetLastError();
+    });
+}
+
+}  // namespace ssmi

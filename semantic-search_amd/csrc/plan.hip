@@ -1,0 +1,66 @@
+// plan.hip - host-side launch planning for K1 (no device code).
+#include "kernels.h"
+#include <cstdlib>
+#include <cstdio>
+
+namespace ssmi {
+
+static int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+bool plan_flat_scan(int dtype, int ld, long long nrows, int nq, int k, int num_cu, ScanPlan* p, std::string* err) {
+    if (k < 1 || k > kMaxK) { *err = "k must be in [1, " + std::to_string(kMaxK) + "]"; return false; }
+    const int V = dtype == 0 ? 4 : 8;
+    const int chunk = 64 * V;
+    const int NF = 4096 / chunk;
+    const int nch_rt = (ld + chunk - 1) / chunk;
+    const int ldq = nch_rt * chunk;
+    const bool whole = (ld % chunk) == 0;
+    p->r = pow2_ceil((k + 63) / 64);
+    const int kp = 64 * p->r;
+
+    int bt = pow2_ceil(nq < 1 ? 1 : nq);
+    const int bt_cap = 8 / p->r < 1 ? 1 : 8 / p->r;
+    if (bt > bt_cap) bt = bt_cap;
+    if (bt > 8) bt = 8;
+    while (bt > 1 && (size_t)bt * ldq * 4 > 128 * 1024) bt >>= 1;
+    if ((size_t)ldq * 4 > 128 * 1024) { *err = "dimension too large for the scan kernel"; return false; }
+    p->bt = bt;
+
+    const char* env_nt = getenv("SSMI_SCAN_NT");
+    p->nt = !(env_nt && env_nt[0] == '0');
+    const char* env_qreg = getenv("SSMI_SCAN_QREG");
+    const bool allow_qreg = !(env_qreg && env_qreg[0] == '0');
+
+    const int nch = whole ? ld / chunk : 0;
+    p->qreg = allow_qreg && bt == 1 && whole && (nch == NF || nch == NF / 2 || nch == NF / 4);
+    int blocks_per_cu;
+    if (p->qreg) {
+        p->nch = nch;
+        p->threads = 256;
+        p->lds = (size_t)4 * kp * sizeof(skey_t);
+        blocks_per_cu = 3;
+    } else {
+        p->nch = 0;
+        const size_t qbytes = (size_t)bt * ldq * 4;
+        p->threads = qbytes > 80 * 1024 ? 1024 : (qbytes > 40 * 1024 ? 512 : 256);
+        const size_t mbytes = (size_t)(p->threads / 64) * kp * sizeof(skey_t);
+        p->lds = qbytes > mbytes ? qbytes : mbytes;
+        blocks_per_cu = (int)((160 * 1024) / (p->lds + 512));
+        const int wave_cap = 32 / (p->threads / 64);
+        if (blocks_per_cu > wave_cap) blocks_per_cu = wave_cap;
+        if (blocks_per_cu > 4) blocks_per_cu = 4;
+        if (blocks_per_cu < 1) blocks_per_cu = 1;
+    }
+    const char* env_bpc = getenv("SSMI_SCAN_BPC");
+    if (env_bpc) { int v = atoi(env_bpc); if (v >= 1 && v <= 16) blocks_per_cu = v; }
+    const int nwaves = p->threads / 64;
+    long long gx = (long long)num_cu * blocks_per_cu;
+    const long long max_useful = (nrows + (long long)nwaves * 4 - 1) / ((long long)nwaves * 4);
+    if (gx > max_useful) gx = max_useful;
+    if (gx < 1) gx = 1;
+    p->grid_x = (int)gx;
+    p->grid_y = (nq + bt - 1) / bt;
+    return true;
+}
+
+}  // namespace ssmi

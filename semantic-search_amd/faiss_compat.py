@@ -1,0 +1,325 @@
+"""`faiss`-shaped Python facade over libssmi.so (HIP kernels on MI355X).
+
+The reference never subclasses or registers anything with FAISS: its boundary is
+the duck type of `faiss.Index` as used by core/index_factory.py and
+core/index_manager.py.  This module re-creates exactly that
+surface:
+
+    IndexFlatIP(d)                                  core/index_factory.py:140,144
+    IndexIVFFlat(quantizer, d, nlist, metric)       core/index_factory.py:145
+    .d .ntotal .is_trained  (.nlist .nprobe on IVF) core/index_factory.py:169-170,223-233
+    .add(x) .train(x) .search(x, k) .reconstruct(i) core/index_manager.py:299,319,371,609
+    read_index(path) / write_index(index, path)     core/index_manager.py:185,241
+    METRIC_INNER_PRODUCT                            core/index_factory.py:145
+
+Class names matter: IndexFactory.detect_index_type (core/index_factory.py:206-217)
+sniffs the substrings "IVFPQ" / "IVFFlat" / "HNSW" in type(index).__name__.
+Flat objects deliberately have no `nlist` / `nprobe` / `hnsw` attributes, because
+get_index_stats / set_search_params branch on hasattr (core/index_factory.py:230-236,317-320).
+
+Additive (not in the reference): `storage="f16"` row storage, torch tensors on a
+ROCm device accepted by add/search (device pointers are handed straight to the
+kernels), `search(..., id_offset=)` for row-sharded databases, `reconstruct_batch`.
+
+All engine failures surface as RuntimeError (what SWIG-FAISS raises and the
+reference catches).  There is no CPU fallback.
+"""
+import ctypes
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+METRIC_INNER_PRODUCT = 0
+METRIC_L2 = 1
+
+_STORAGE = {"f32": _lib.F32, "fp32": _lib.F32, "float32": _lib.F32, "f16": _lib.F16, "fp16": _lib.F16,
+            "float16": _lib.F16}
+
+
+def _default_device() -> int:
+    env = os.environ.get("SSMI_DEVICE")
+    if env is not None:
+        return int(env)
+    if torch.cuda.is_available():
+        return int(torch.cuda.current_device())
+    return 0
+
+
+def _as_f32_matrix(x, d: int, what: str) -> np.ndarray:
+    x = np.asarray(x)
+    if x.ndim == 1:
+        x = x.reshape(1, -1)
+    if x.ndim != 2:
+        raise ValueError(f"{what}: expected a 2-D array, got shape {x.shape}")
+    # the FAISS SWIG wrapper asserts on the dimension
+    assert x.shape[1] == d, f"{what}: dimension {x.shape[1]} != index dimension {d}"
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+class _IndexBase:
+    """Common handle plumbing of the two index classes."""
+
+    metric_type = METRIC_INNER_PRODUCT
+
+    def __init__(self):
+        self._h = ctypes.c_void_p()
+        self._lib = _lib.load()
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self) -> None:
+        h, self._h = getattr(self, "_h", None), ctypes.c_void_p()
+        if h:
+            self._lib.ssmi_index_free(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _handle(self):
+        if not self._h:
+            raise RuntimeError("index has been closed")
+        return self._h
+
+    # -- attributes -------------------------------------------------------
+    def _get_int(self, fn) -> int:
+        out = ctypes.c_int()
+        _lib.check(fn(self._handle(), ctypes.byref(out)))
+        return int(out.value)
+
+    @property
+    def d(self) -> int:
+        return self._get_int(self._lib.ssmi_index_get_d)
+
+    @property
+    def ntotal(self) -> int:
+        out = ctypes.c_int64()
+        _lib.check(self._lib.ssmi_index_get_ntotal(self._handle(), ctypes.byref(out)))
+        return int(out.value)
+
+    @property
+    def is_trained(self) -> bool:
+        return bool(self._get_int(self._lib.ssmi_index_get_is_trained))
+
+    @property
+    def device(self) -> int:
+        return self._get_int(self._lib.ssmi_index_get_device)
+
+    @property
+    def storage(self) -> str:
+        return "f16" if self._get_int(self._lib.ssmi_index_get_storage_dtype) == _lib.F16 else "f32"
+
+    # -- add / train ------------------------------------------------------
+    def train(self, x) -> None:
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            self._check_tensor(x, "train")
+            x = x.contiguous().float()
+            torch.cuda.current_stream(x.device).synchronize()
+            _lib.check(self._lib.ssmi_index_train(self._handle(), x.shape[0], x.data_ptr(), _lib.DEVICE))
+            return
+        if isinstance(x, torch.Tensor):
+            x = x.numpy()
+        x = _as_f32_matrix(x, self.d, "train")
+        _lib.check(self._lib.ssmi_index_train(self._handle(), x.shape[0], x.ctypes.data, _lib.HOST))
+
+    def _check_tensor(self, x: torch.Tensor, what: str) -> None:
+        if x.dim() != 2:
+            raise ValueError(f"{what}: expected a 2-D tensor, got shape {tuple(x.shape)}")
+        assert x.shape[1] == self.d, f"{what}: dimension {x.shape[1]} != index dimension {self.d}"
+        if x.device.index != self.device:
+            raise RuntimeError(f"{what}: tensor is on {x.device}, index lives on cuda:{self.device}")
+
+    def add(self, x) -> None:
+        """Append vectors; ids are the running row numbers (FAISS add() without ids)."""
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            self._check_tensor(x, "add")
+            if x.dtype not in (torch.float32, torch.float16):
+                x = x.float()
+            x = x.contiguous()
+            torch.cuda.current_stream(x.device).synchronize()  # the library copies on its own stream
+            dt = _lib.F32 if x.dtype == torch.float32 else _lib.F16
+            _lib.check(self._lib.ssmi_index_add(self._handle(), x.shape[0], x.data_ptr(), dt, _lib.DEVICE))
+            return
+        if isinstance(x, torch.Tensor):
+            x = x.numpy()
+        x = _as_f32_matrix(x, self.d, "add")
+        _lib.check(self._lib.ssmi_index_add(self._handle(), x.shape[0], x.ctypes.data, _lib.F32, _lib.HOST))
+
+    def add_random_unit(self, n: int, seed: int = 1234) -> None:
+        """Bench/test helper: n rows of N(0,1) components, L2-normalised, generated on the device."""
+        _lib.check(self._lib.ssmi_index_add_random_unit(self._handle(), int(n), int(seed)))
+
+    # -- search -----------------------------------------------------------
+    def search(self, x, k: int, id_offset: int = 0):
+        """(D, I) = top-k inner products of each query row.
+
+        numpy in -> numpy out (D float32 (n,k) sorted descending, I int64, -1 padded).
+        A torch tensor on the index's device -> torch tensors on that device,
+        enqueued on the current torch stream (no host synchronisation).
+        """
+        k = int(k)
+        if k < 1:
+            raise RuntimeError("search: k must be >= 1")
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            if x.dim() == 1:
+                x = x.reshape(1, -1)
+            self._check_tensor(x, "search")
+            x = x.contiguous().float()
+            nq = x.shape[0]
+            D = torch.empty((nq, k), dtype=torch.float32, device=x.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=x.device)
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _lib.check(self._lib.ssmi_index_search(self._handle(), nq, x.data_ptr(), _lib.DEVICE, k, D.data_ptr(),
+                                                   I.data_ptr(), _lib.DEVICE, int(id_offset), stream))
+            return D, I
+        if isinstance(x, torch.Tensor):
+            x = x.numpy()
+        x = _as_f32_matrix(x, self.d, "search")
+        nq = x.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        _lib.check(self._lib.ssmi_index_search(self._handle(), nq, x.ctypes.data, _lib.HOST, k, D.ctypes.data,
+                                               I.ctypes.data, _lib.HOST, int(id_offset), None))
+        return D, I
+
+    # -- read back --------------------------------------------------------
+    def reconstruct_batch(self, ids) -> np.ndarray:
+        ids = np.ascontiguousarray(np.asarray(ids, dtype=np.int64).reshape(-1))
+        out = np.empty((ids.shape[0], self.d), dtype=np.float32)
+        _lib.check(self._lib.ssmi_index_reconstruct_n(self._handle(), ids.shape[0], ids.ctypes.data, out.ctypes.data))
+        return out
+
+    def reconstruct(self, i: int) -> np.ndarray:
+        """Stored vector i as float32 (d,).  RuntimeError when it cannot be produced,
+        which is what the reference catches (core/index_factory.py:275)."""
+        return self.reconstruct_batch([int(i)])[0]
+
+    def reconstruct_n(self, i0: int = 0, ni: int = -1) -> np.ndarray:
+        if ni < 0:
+            ni = self.ntotal - i0
+        return self.reconstruct_batch(np.arange(i0, i0 + ni, dtype=np.int64))
+
+    # -- timing of the last search (bench / tests) --------------------------
+    def last_timing(self) -> dict:
+        t = _lib.Timing()
+        _lib.check(self._lib.ssmi_index_get_timing(self._handle(), ctypes.byref(t)))
+        return {name: getattr(t, name) for name, _ in _lib.Timing._fields_}
+
+
+    def scan_times_ms(self, max_n: int = 256) -> np.ndarray:
+        """hipEvent durations of the dominant kernel of the last searches (oldest first)."""
+        out = np.zeros((max_n,), dtype=np.float32)
+        n = ctypes.c_int()
+        _lib.check(self._lib.ssmi_index_get_scan_times(self._handle(), int(max_n), out.ctypes.data, ctypes.byref(n)))
+        return out[: n.value].copy()
+
+
+class IndexFlatIP(_IndexBase):
+    """Exact maximum-inner-product index (stand-in for faiss.IndexFlatIP)."""
+
+    def __init__(self, d: int, storage: str = "f32", device: Optional[int] = None, _handle=None):
+        super().__init__()
+        if _handle is not None:
+            self._h = _handle
+            return
+        dev = _default_device() if device is None else int(device)
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.ssmi_index_create_flat(int(d), _STORAGE[storage], dev, ctypes.byref(h)))
+        self._h = h
+
+
+class IndexIVFFlat(_IndexBase):
+    """Inverted-file index with exact inner products inside the probed lists
+    (stand-in for faiss.IndexIVFFlat with METRIC_INNER_PRODUCT)."""
+
+    def __init__(self, quantizer, d: int, nlist: int, metric: int = METRIC_INNER_PRODUCT, storage: str = "f32",
+                 device: Optional[int] = None, _handle=None):
+        super().__init__()
+        self.quantizer = quantizer
+        if _handle is not None:
+            self._h = _handle
+            return
+        if metric != METRIC_INNER_PRODUCT:
+            raise RuntimeError("IndexIVFFlat: only METRIC_INNER_PRODUCT is supported")
+        if quantizer is not None and getattr(quantizer, "d", d) != d:
+            raise RuntimeError("IndexIVFFlat: quantizer dimension differs from d")
+        if device is None:
+            device = quantizer.device if isinstance(quantizer, _IndexBase) else _default_device()
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.ssmi_index_create_ivfflat(int(d), int(nlist), _STORAGE[storage], int(device),
+                                                       ctypes.byref(h)))
+        self._h = h
+
+    @property
+    def nlist(self) -> int:
+        return self._get_int(self._lib.ssmi_index_get_nlist)
+
+    @property
+    def nprobe(self) -> int:
+        return self._get_int(self._lib.ssmi_index_get_nprobe)
+
+    @nprobe.setter
+    def nprobe(self, v: int) -> None:
+        _lib.check(self._lib.ssmi_index_set_nprobe(self._handle(), int(v)))
+
+    def make_direct_map(self, _enable: bool = True) -> None:
+        """Like faiss: without a direct map reconstruct() raises RuntimeError."""
+        _lib.check(self._lib.ssmi_index_make_direct_map(self._handle()))
+
+    def set_centroids(self, centroids) -> None:
+        c = np.ascontiguousarray(np.asarray(centroids, dtype=np.float32))
+        if c.shape != (self.nlist, self.d):
+            raise ValueError(f"centroids must have shape {(self.nlist, self.d)}")
+        _lib.check(self._lib.ssmi_index_set_centroids(self._handle(), c.ctypes.data, _lib.HOST))
+
+    def get_centroids(self) -> np.ndarray:
+        out = np.empty((self.nlist, self.d), dtype=np.float32)
+        _lib.check(self._lib.ssmi_index_get_centroids(self._handle(), out.ctypes.data))
+        return out
+
+    def list_sizes(self) -> np.ndarray:
+        out = np.empty((self.nlist,), dtype=np.int64)
+        _lib.check(self._lib.ssmi_index_get_list_sizes(self._handle(), out.ctypes.data))
+        return out
+
+
+def write_index(index: _IndexBase, path) -> None:
+    """Stand-in for faiss.write_index (core/index_manager.py:241)."""
+    _lib.check(index._lib.ssmi_index_write(index._handle(), os.fsencode(str(path))))
+
+
+def read_index(path, storage: Optional[str] = None, device: Optional[int] = None) -> _IndexBase:
+    """Stand-in for faiss.read_index (core/index_manager.py:185)."""
+    lib = _lib.load()
+    dev = _default_device() if device is None else int(device)
+    h = ctypes.c_void_p()
+    sd = -1 if storage is None else _STORAGE[storage]
+    _lib.check(lib.ssmi_index_read(os.fsencode(str(path)), sd, dev, ctypes.byref(h)))
+    kind = ctypes.c_int()
+    _lib.check(lib.ssmi_index_get_kind(h, ctypes.byref(kind)))
+    if kind.value == _lib.KIND_IVFFLAT:
+        return IndexIVFFlat(None, 0, 0, _handle=h)
+    return IndexFlatIP(0, _handle=h)
+
+
+def topk_merge(D_lists: torch.Tensor, I_lists: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Merge `nlists` result sets laid out (nlists, nq, k) on a ROCm device into the
+    (nq, k) top-k of their union (the consumer of the RCCL all-gather)."""
+    if D_lists.dim() != 3 or D_lists.shape != I_lists.shape:
+        raise ValueError("topk_merge: expected (nlists, nq, k) tensors of equal shape")
+    if not D_lists.is_cuda or D_lists.device != I_lists.device:
+        raise RuntimeError("topk_merge: tensors must live on the same ROCm device")
+    D_lists = D_lists.contiguous().float()
+    I_lists = I_lists.contiguous().long()
+    nl, nq, k = D_lists.shape
+    D = torch.empty((nq, k), dtype=torch.float32, device=D_lists.device)
+    I = torch.empty((nq, k), dtype=torch.int64, device=D_lists.device)
+    stream = torch.cuda.current_stream(D_lists.device).cuda_stream
+    _lib.check(_lib.load().ssmi_topk_merge(D_lists.device.index, nl, nq, k, D_lists.data_ptr(), I_lists.data_ptr(),
+                                           D.data_ptr(), I.data_ptr(), stream))
+    return D, I

@@ -1,0 +1,235 @@
+"""Index factory: the reference's core/index_factory.py surface over the HIP engine.
+
+Same names, arguments, defaults and failure behaviour as the reference module
+(cited per member as file:line under /root/reference), with `faiss` replaced by
+`semantic_search_amd.faiss_compat`.  Differences, all deliberate:
+  - HNSW and IVF-PQ are outside the north-star scope (Flat + IVF-Flat).  The enum
+    members and config fields stay (config.json compatibility); create_index
+    raises NotImplementedError for them instead of shipping an untested path.
+  - rebuild/compact read vectors back with ONE bulk gather (reconstruct_batch)
+    instead of ntotal single-row calls (core/index_factory.py:273-274,371-372).
+  - `storage` / `device` can be passed through IndexConfig.extra (additive).
+"""
+from dataclasses import dataclass, field
+from enum import Enum
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import faiss_compat as faiss
+
+
+class IndexType(Enum):
+    """core/index_factory.py:18-33"""
+    FLAT = "flat"
+    IVF_FLAT = "ivf_flat"
+    HNSW = "hnsw"
+    IVF_PQ = "ivf_pq"
+
+    @classmethod
+    def from_string(cls, s: str) -> "IndexType":
+        """Case-insensitive, '-' == '_'; anything unknown means FLAT (core/index_factory.py:26-33)."""
+        key = s.lower().replace("-", "_")
+        return next((m for m in cls if m.value == key), cls.FLAT)
+
+
+@dataclass
+class IndexConfig:
+    """core/index_factory.py:36-90 (field names and defaults are part of config.json)."""
+    index_type: IndexType
+    dimension: int
+    nlist: int = 100
+    nprobe: int = 10
+    hnsw_m: int = 32
+    hnsw_ef_construction: int = 200
+    hnsw_ef_search: int = 64
+    pq_m: int = 8
+    pq_bits: int = 8
+    is_trained: bool = False
+    training_size: int = 0
+    # additive, not serialised: engine options {"storage": "f32"|"f16", "device": int}
+    extra: Dict[str, Any] = field(default_factory=dict, repr=False, compare=False)
+
+    _KEYS = ("nlist", "nprobe", "hnsw_m", "hnsw_ef_construction", "hnsw_ef_search", "pq_m", "pq_bits",
+             "is_trained", "training_size")
+
+    def to_dict(self) -> Dict[str, Any]:
+        out: Dict[str, Any] = {"index_type": self.index_type.value, "dimension": self.dimension}
+        out.update({k: getattr(self, k) for k in self._KEYS})
+        return out
+
+    @classmethod
+    def from_dict(cls, d: Dict[str, Any]) -> "IndexConfig":
+        defaults = cls(index_type=IndexType.FLAT, dimension=4096)
+        kwargs = {k: d.get(k, getattr(defaults, k)) for k in cls._KEYS}
+        return cls(index_type=IndexType.from_string(d.get("index_type", "flat")),
+                   dimension=d.get("dimension", 4096), **kwargs)
+
+
+# core/index_factory.py:94-119 (imported by nodes/index_nodes.py:28)
+INDEX_TYPE_DESCRIPTIONS = {
+    IndexType.FLAT: {
+        "name": "Flat (Exact)",
+        "description": "Exact search on the GPU, 100% accurate. HBM-bandwidth bound; fine up to tens of millions of vectors per MI355X.",
+        "needs_training": False,
+        "supports_removal": False,
+    },
+    IndexType.IVF_FLAT: {
+        "name": "IVF-Flat (Fast)",
+        "description": "Approximate search using clustering: probes nprobe of nlist inverted lists. Needs training.",
+        "needs_training": True,
+        "supports_removal": False,
+    },
+    IndexType.HNSW: {
+        "name": "HNSW (not built)",
+        "description": "Graph index; outside the scope of the MI355X engine (use Flat or IVF-Flat).",
+        "needs_training": False,
+        "supports_removal": False,
+    },
+    IndexType.IVF_PQ: {
+        "name": "IVF-PQ (not built)",
+        "description": "Product-quantised index; outside the scope of the MI355X engine (use IVF-Flat with f16 storage).",
+        "needs_training": True,
+        "supports_removal": False,
+    },
+}
+
+ProgressCallback = Optional[Callable[[int, int, str], None]]
+_TRAIN_SAMPLE_CAP = 100000  # core/index_factory.py:293,401
+
+
+class IndexFactory:
+    """core/index_factory.py:122-416"""
+
+    @staticmethod
+    def create_index(config: IndexConfig):
+        """core/index_factory.py:125-163"""
+        opts = {k: v for k, v in config.extra.items() if k in ("storage", "device")}
+        if config.index_type == IndexType.FLAT:
+            return faiss.IndexFlatIP(config.dimension, **opts)
+        if config.index_type == IndexType.IVF_FLAT:
+            quantizer = faiss.IndexFlatIP(config.dimension, **opts)
+            index = faiss.IndexIVFFlat(quantizer, config.dimension, config.nlist, faiss.METRIC_INNER_PRODUCT, **opts)
+            index.nprobe = config.nprobe
+            return index
+        if config.index_type in (IndexType.HNSW, IndexType.IVF_PQ):
+            raise NotImplementedError(
+                f"index type {config.index_type.value!r} is outside the MI355X engine's scope (flat, ivf_flat)")
+        raise ValueError(f"Unknown index type: {config.index_type}")
+
+    @staticmethod
+    def needs_training(index) -> bool:
+        """core/index_factory.py:165-171"""
+        return (not index.is_trained) if hasattr(index, "is_trained") else False
+
+    @staticmethod
+    def train_index(index, vectors: np.ndarray) -> bool:
+        """core/index_factory.py:173-195: True if already trained; any exception means False."""
+        if not IndexFactory.needs_training(index):
+            return True
+        try:
+            index.train(np.ascontiguousarray(vectors.astype(np.float32)))
+            return bool(index.is_trained)
+        except Exception as e:  # the reference swallows everything here
+            print(f"[SemanticSearch] Index training failed: {e}")
+            return False
+
+    @staticmethod
+    def get_min_training_size(config: IndexConfig) -> int:
+        """core/index_factory.py:197-203"""
+        if config.index_type in (IndexType.IVF_FLAT, IndexType.IVF_PQ):
+            return max(config.nlist * 10, 1000)
+        return 0
+
+    @staticmethod
+    def detect_index_type(index) -> IndexType:
+        """core/index_factory.py:205-217 (class-name sniffing, same precedence)."""
+        name = type(index).__name__
+        for needle, kind in (("IVFPQ", IndexType.IVF_PQ), ("IVFFlat", IndexType.IVF_FLAT), ("HNSW", IndexType.HNSW)):
+            if needle in name:
+                return kind
+        return IndexType.FLAT
+
+    @staticmethod
+    def get_index_stats(index) -> Dict[str, Any]:
+        """core/index_factory.py:219-238"""
+        stats: Dict[str, Any] = {
+            "total_vectors": index.ntotal,
+            "dimension": index.d,
+            "index_type": IndexFactory.detect_index_type(index).value,
+            "is_trained": getattr(index, "is_trained", True),
+        }
+        for attr in ("nlist", "nprobe"):
+            if hasattr(index, attr):
+                stats[attr] = getattr(index, attr)
+        if hasattr(index, "hnsw"):
+            stats["hnsw_m"] = getattr(index.hnsw, "M", None)
+            stats["hnsw_ef_search"] = index.hnsw.efSearch
+        return stats
+
+    @staticmethod
+    def set_search_params(index, config: IndexConfig) -> None:
+        """core/index_factory.py:314-320"""
+        if hasattr(index, "nprobe"):
+            index.nprobe = config.nprobe
+        if hasattr(index, "hnsw") and hasattr(index.hnsw, "efSearch"):
+            index.hnsw.efSearch = config.hnsw_ef_search
+
+    # -- shared tail of rebuild/compact -------------------------------------
+    @staticmethod
+    def _build_from(vectors: np.ndarray, config: IndexConfig):
+        index = IndexFactory.create_index(config)
+        if IndexFactory.needs_training(index):
+            sample = vectors
+            if len(vectors) > _TRAIN_SAMPLE_CAP:
+                sample = vectors[np.random.choice(len(vectors), _TRAIN_SAMPLE_CAP, replace=False)]
+            if not IndexFactory.train_index(index, sample):
+                print("[SemanticSearch] Warning: Training failed, falling back to Flat index")
+                config.index_type = IndexType.FLAT
+                index = IndexFactory.create_index(config)
+        index.add(vectors)
+        return index
+
+    @staticmethod
+    def rebuild_index(old_index, new_config: IndexConfig, progress_callback: ProgressCallback = None) -> Tuple[Any, bool]:
+        """core/index_factory.py:240-312.  Returns (new_index, True) or (old_index, False)."""
+        n = old_index.ntotal
+        report = progress_callback or (lambda *a: None)
+        if n == 0:
+            return IndexFactory.create_index(new_config), True
+        report(0, n, "Extracting vectors from old index...")
+        try:
+            vectors = old_index.reconstruct_batch(np.arange(n, dtype=np.int64))
+        except RuntimeError:
+            print("[SemanticSearch] Warning: Cannot reconstruct vectors from this index type")
+            return old_index, False
+        report(n // 2, n, "Creating new index...")
+        if new_config.index_type in (IndexType.IVF_FLAT, IndexType.IVF_PQ):
+            report(n // 2, n, "Training new index...")
+        new_index = IndexFactory._build_from(vectors, new_config)
+        report(n * 3 // 4, n, "Adding vectors to new index...")
+        report(n, n, "Rebuild complete")
+        return new_index, True
+
+    @staticmethod
+    def compact_index(old_index, valid_vector_ids: List[int], new_config: Optional[IndexConfig] = None,
+                      progress_callback: ProgressCallback = None) -> Tuple[Any, Dict[int, int], bool]:
+        """core/index_factory.py:322-416.  Keeps sorted(valid ids), renumbers them 0..n-1."""
+        n_valid, n_total = len(valid_vector_ids), old_index.ntotal
+        report = progress_callback or (lambda *a: None)
+        if new_config is None:
+            new_config = IndexConfig(index_type=IndexFactory.detect_index_type(old_index), dimension=old_index.d)
+        if n_valid == 0:
+            return IndexFactory.create_index(new_config), {}, True
+        report(0, n_valid, f"Extracting {n_valid} vectors (removing {n_total - n_valid} deleted)...")
+        keep = sorted(valid_vector_ids)
+        id_mapping = {old: new for new, old in enumerate(keep)}
+        try:
+            vectors = old_index.reconstruct_batch(np.asarray(keep, dtype=np.int64))
+        except RuntimeError as e:
+            print(f"[SemanticSearch] Warning: Cannot reconstruct vectors: {e}")
+            return old_index, {}, False
+        report(n_valid, n_valid, "Creating compacted index...")
+        new_index = IndexFactory._build_from(vectors, new_config)
+        report(n_valid, n_valid, f"Compaction complete: {n_total} -> {n_valid} vectors")
+        return new_index, id_mapping, True

@@ -1,0 +1,86 @@
+"""Row-sharded Flat search across the GPUs of one node: one process per GPU.
+
+Each rank owns one contiguous block of database rows in its own IndexFlatIP
+(global id = local row + the rank's row offset, which keeps the reference's
+implicit sequential ids, core/index_manager.py:319-325).  A search is
+    local top-k (HIP kernels)  ->  all_gather of the (B,k) scores and ids over
+    RCCL/xGMI  ->  merge of the `world` lists (ssmi_topk_merge)
+The collective moves 12*B*k bytes per rank (120 B at B=1, k=10), so it is
+latency-bound; there is no other data-path communication.
+
+The reference has no distributed code; this is new.
+"""
+from typing import Callable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(ntotal: int, world: int) -> List[int]:
+    """Contiguous, near-equal row blocks: bounds[r] .. bounds[r+1] is rank r's block."""
+    base, rem = divmod(int(ntotal), int(world))
+    bounds = [0]
+    for r in range(world):
+        bounds.append(bounds[-1] + base + (1 if r < rem else 0))
+    return bounds
+
+
+def exchange_offsets(n_local: int, group=None, device="cpu") -> Tuple[int, int]:
+    """(row offset of this rank, global ntotal) from every rank's local row count."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(counts, mine, group=group)
+    counts = [int(c.item()) for c in counts]
+    return sum(counts[:rank]), sum(counts)
+
+
+def gather_topk(D: torch.Tensor, I: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """all_gather per-rank (B,k) results into (world, B, k) tensors (one collective each)."""
+    world = dist.get_world_size(group)
+    Dg = torch.empty((world,) + tuple(D.shape), dtype=D.dtype, device=D.device)
+    Ig = torch.empty((world,) + tuple(I.shape), dtype=I.dtype, device=I.device)
+    dist.all_gather_into_tensor(Dg, D.contiguous(), group=group)
+    dist.all_gather_into_tensor(Ig, I.contiguous(), group=group)
+    return Dg, Ig
+
+
+class ShardedFlatIP:
+    """Exact inner-product search over a database row-sharded across ranks."""
+
+    def __init__(self, d: int, storage: str = "f32", group=None, device: Optional[int] = None,
+                 _local_index=None, _merge: Optional[Callable] = None):
+        self.d = d
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if _local_index is None:
+            from .faiss_compat import IndexFlatIP, topk_merge
+            _local_index = IndexFlatIP(d, storage=storage, device=device)
+            _merge = topk_merge
+        self.local = _local_index
+        self._merge = _merge
+        self.row_offset = 0
+        self.ntotal = 0
+
+    def add_local(self, x) -> None:
+        self.local.add(x)
+
+    def add_local_random_unit(self, n: int, seed: int) -> None:
+        self.local.add_random_unit(n, seed)
+
+    def finalize(self, device="cpu") -> None:
+        """Agree on row offsets after the ranks have added their blocks."""
+        if self.world > 1:
+            self.row_offset, self.ntotal = exchange_offsets(self.local.ntotal, self.group, device)
+        else:
+            self.row_offset, self.ntotal = 0, self.local.ntotal
+
+    def search(self, q, k: int):
+        """q: (B,d) tensor, identical on every rank.  Returns the global (D, I) on every rank."""
+        D, I = self.local.search(q, k, id_offset=self.row_offset)
+        if self.world == 1:
+            return D, I
+        Dg, Ig = gather_topk(D, I, self.group)
+        return self._merge(Dg, Ig)

@@ -1,0 +1,167 @@
+"""GPU parity: HIP Flat search (through the C-ABI via ctypes) vs the CPU oracle.
+
+Tolerance (BASELINE.json north_star): ids bit-exact except at score ties within
+1e-3 relative, scores within 1e-3 relative.  The tests use a much tighter 1e-5 for
+fp32 storage (the only difference is fp32 summation order).
+"""
+import numpy as np
+import pytest
+
+from conftest import unit_rows
+from oracle import flat_ip
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def _check(index, X, Q, k, rtol=RTOL):
+    D, I = index.search(Q, k)
+    assert D.shape == (len(np.atleast_2d(Q)), k) and D.dtype == np.float32
+    assert I.shape == D.shape and I.dtype == np.int64
+    Dr, Ir = flat_ip.search(X, Q, k)
+    ok, msg, nm = flat_ip.check_against(D, I, Dr, Ir, X, Q, rtol=rtol, tie_rtol=rtol)
+    assert ok, msg
+    return nm
+
+
+@pytest.mark.parametrize("n,d,nq,k", [
+    (10000, 4096, 1, 10),      # the register-query kernel, batch 1
+    (10000, 4096, 100, 10),    # BASELINE config 1 shape (LDS-query kernel, 8 queries per pass)
+    (3000, 4096, 3, 100),
+    (3000, 4096, 1, 500),      # UI maximum k (core/config.py:64)
+    (2000, 2048, 1, 10),
+    (2000, 1024, 2, 10),
+    (5000, 256, 5, 10),        # Matryoshka-truncated dimension
+    (777, 64, 4, 10),
+    (513, 100, 3, 7),          # d not a multiple of 8 -> padded rows
+    (300, 3, 2, 5),
+    (1000, 4096, 1, 1),
+    (1500, 4096, 1, 1024),     # largest supported k
+])
+def test_flat_f32_matches_oracle(ssa, n, d, nq, k):
+    X = unit_rows(n, d, 1234)
+    Q = unit_rows(nq, d, 4321)
+    index = ssa.IndexFlatIP(d)
+    index.add(X)
+    assert index.ntotal == n and index.d == d and index.is_trained
+    _check(index, X, Q, k)
+    index.close()
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(10000, 4096, 1, 10), (10000, 4096, 8, 10), (3000, 4096, 2, 100),
+                                      (2000, 2048, 1, 10), (777, 72, 3, 10)])
+def test_flat_f16_storage_matches_oracle_on_rounded_rows(ssa, n, d, nq, k):
+    """fp16 storage: the kernel must be exact against the oracle run on the fp16-rounded rows."""
+    X = unit_rows(n, d, 1234)
+    Xh = X.astype(np.float16).astype(np.float32)
+    Q = unit_rows(nq, d, 4321)
+    index = ssa.IndexFlatIP(d, storage="f16")
+    index.add(X)
+    _check(index, Xh, Q, k)
+    # and reconstruct returns exactly the rounded rows
+    np.testing.assert_array_equal(index.reconstruct_batch([0, n // 2, n - 1]), Xh[[0, n // 2, n - 1]])
+    index.close()
+
+
+def test_k_larger_than_ntotal_pads_with_minus_one(ssa):
+    X = unit_rows(5, 128, 1)
+    index = ssa.IndexFlatIP(128)
+    index.add(X)
+    D, I = index.search(unit_rows(2, 128, 2), 10)
+    assert (I[:, 5:] == -1).all() and (I[:, :5] >= 0).all()
+    assert (D[:, 5:] == flat_ip.NEG_MAX).all()
+    assert all(sorted(row[:5]) == [0, 1, 2, 3, 4] for row in I)
+    assert (np.diff(D[:, :5], axis=1) <= 0).all()
+
+
+def test_empty_index(ssa):
+    index = ssa.IndexFlatIP(64)
+    D, I = index.search(unit_rows(3, 64, 2), 4)
+    assert (I == -1).all() and (D == flat_ip.NEG_MAX).all() and index.ntotal == 0
+
+
+def test_one_dimensional_query_is_one_row(ssa):
+    X = unit_rows(100, 256, 1)
+    index = ssa.IndexFlatIP(256)
+    index.add(X)
+    D, I = index.search(X[7], 3)  # core/index_manager.py:364-365 reshapes 1-D queries
+    assert D.shape == (1, 3) and I[0, 0] == 7 and abs(D[0, 0] - 1.0) < 1e-5
+
+
+def test_duplicate_rows_tie_order_is_ascending_id(ssa):
+    X = unit_rows(50, 128, 3)
+    X[10] = X[3]; X[40] = X[3]; X[41] = X[3]
+    index = ssa.IndexFlatIP(128)
+    index.add(X)
+    D, I = index.search(X[3], 5)
+    assert list(I[0, :4]) == [3, 10, 40, 41]
+    assert (D[0, :4] == D[0, 0]).all()
+
+
+def test_incremental_add_and_segment_table(ssa, monkeypatch):
+    """Rows added in many small batches across several storage segments."""
+    monkeypatch.setenv("SSMI_SEG_SHIFT", "8")  # 256-row segments
+    d = 128
+    X = unit_rows(1500, d, 5)
+    index = ssa.IndexFlatIP(d)
+    for s in range(0, 1500, 97):
+        index.add(X[s:s + 97])
+    assert index.ntotal == 1500
+    _check(index, X, unit_rows(4, d, 6), 10)
+    np.testing.assert_array_equal(index.reconstruct_n(250, 20), X[250:270])
+    with pytest.raises(RuntimeError):
+        index.reconstruct(1500)
+
+
+def test_torch_device_tensors(ssa):
+    import torch
+    X = unit_rows(4000, 1024, 7)
+    Q = unit_rows(3, 1024, 8)
+    index = ssa.IndexFlatIP(1024)
+    index.add(torch.from_numpy(X).cuda())
+    D, I = index.search(torch.from_numpy(Q).cuda(), 10, id_offset=1000)
+    assert D.is_cuda and I.is_cuda and I.dtype == torch.int64
+    Dr, Ir = flat_ip.search(X, Q, 10)
+    ok, msg, _ = flat_ip.check_against(D.cpu().numpy(), I.cpu().numpy() - 1000, Dr, Ir, X, Q, RTOL, RTOL)
+    assert ok, msg
+
+
+def test_topk_merge_of_shards_equals_unsharded(ssa):
+    """Logical 3-way row sharding on one GPU + the all-gather consumer kernel."""
+    import torch
+    from semantic_search_amd.faiss_compat import topk_merge
+    d, k = 512, 20
+    X = unit_rows(3001, d, 9)
+    Q = unit_rows(5, d, 10)
+    bounds = [0, 1000, 1007, 3001]
+    Ds, Is = [], []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        shard = ssa.IndexFlatIP(d)
+        shard.add(X[a:b])
+        D, I = shard.search(torch.from_numpy(Q).cuda(), k, id_offset=a)
+        Ds.append(D); Is.append(I)
+    D, I = topk_merge(torch.stack(Ds), torch.stack(Is))
+    Dr, Ir = flat_ip.search(X, Q, k)
+    ok, msg, _ = flat_ip.check_against(D.cpu().numpy(), I.cpu().numpy(), Dr, Ir, X, Q, RTOL, RTOL)
+    assert ok, msg
+
+
+def test_errors_are_runtime_errors(ssa):
+    index = ssa.IndexFlatIP(64)
+    index.add(unit_rows(10, 64, 1))
+    with pytest.raises(RuntimeError):
+        index.search(unit_rows(1, 64, 2), 2000)  # k above the engine maximum
+    with pytest.raises(AssertionError):
+        index.add(unit_rows(2, 32, 1))  # wrong dimension (FAISS asserts too)
+
+
+def test_large_random_unit_matches_oracle_on_readback(ssa):
+    """Device-generated rows (the bench's data path): read back, then oracle."""
+    d, n = 4096, 20000
+    index = ssa.IndexFlatIP(d)
+    index.add_random_unit(n, seed=1234)
+    X = index.reconstruct_n(0, n)
+    assert np.allclose(np.linalg.norm(X, axis=1), 1.0, atol=1e-4)
+    assert abs(float(X.mean())) < 1e-3 and abs(float(X.std()) * np.sqrt(d) - 1.0) < 0.02
+    _check(index, X, unit_rows(2, d, 4321), 10)
