@@ -39,11 +39,13 @@ def exchange_offsets(n_local: int, group=None, device="cpu") -> Tuple[int, int]:
 def gather_topk(D: torch.Tensor, I: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """all_gather per-rank (B,k) results into (world, B, k) tensors (one collective each)."""
     world = dist.get_world_size(group)
-    Dg = torch.empty((world,) + tuple(D.shape), dtype=D.dtype, device=D.device)
-    Ig = torch.empty((world,) + tuple(I.shape), dtype=I.dtype, device=I.device)
+    B, k = D.shape
+    # concatenation layout (world*B, k): accepted by both the RCCL and the gloo backend
+    Dg = torch.empty((world * B, k), dtype=D.dtype, device=D.device)
+    Ig = torch.empty((world * B, k), dtype=I.dtype, device=I.device)
     dist.all_gather_into_tensor(Dg, D.contiguous(), group=group)
     dist.all_gather_into_tensor(Ig, I.contiguous(), group=group)
-    return Dg, Ig
+    return Dg.view(world, B, k), Ig.view(world, B, k)
 
 
 class ShardedFlatIP:
