@@ -345,9 +345,46 @@ int ssmi_index_train(ssmi_index* h, int64_t n, const float* x, int mem_kind) {
 }
 
 // ------------------------------------------------------------------ search
+static int mfma_min_batch() {
+    const char* e = getenv("SSMI_MFMA_MIN_B");
+    int v = e ? atoi(e) : 9;
+    return v < 1 ? 1 : v;
+}
+
+static int flat_search_mfma(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev, int64_t* Idev,
+                            int64_t id_offset, hipStream_t s) {
+    const RowStore& R = h->rows;
+    const int64_t kMaxBatch = 4096;  // 16 query tiles -> 16 database slices on 256 CUs
+    hipEvent_t* ev = h->ev[h->n_searches % ssmi_index::kEvRing];
+    MfmaPlan p = {};
+    for (int64_t done = 0; done < nq; done += kMaxBatch) {
+        const int nb = (int)std::min<int64_t>(kMaxBatch, nq - done);
+        if (!plan_flat_mfma(R.dtype, R.ld, R.nrows, nb, k, h->num_cu, &p)) return fail("internal: MFMA plan failed");
+        CHECK(ensure_ws(h, 4, p.qh_bytes));
+        CHECK(ensure_ws(h, 5, p.cand_bytes));
+        CHECK(ensure_ws(h, 2, (size_t)nb * p.nslices * k * sizeof(skey_t)));
+        skey_t* partial = (skey_t*)h->ws[2];
+        if (done == 0) HIPCHECK(hipEventRecord(ev[0], s));
+        HIPCHECK(launch_flat_mfma(R.view(), qdev + (size_t)done * R.ld, nb, k, p, h->ws[4], h->ws[5], partial, s));
+        if (done == 0) HIPCHECK(hipEventRecord(ev[1], s));
+        HIPCHECK(launch_merge_keys(partial, nb, p.nslices, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
+                                   id_offset, s));
+        if (done == 0) HIPCHECK(hipEventRecord(ev[2], s));
+    }
+    h->n_searches++;
+    h->timing_valid = true;
+    h->timing.last_path = 1;
+    h->timing.last_grid = p.grid;
+    h->timing.last_scan_bytes = (int64_t)R.nrows * R.d * R.elsize;
+    h->timing.last_scan_flops = 2ll * std::min<int64_t>(nq, kMaxBatch) * R.nrows * R.d;
+    return 0;
+}
+
 static int flat_search(ssmi_index* h, int64_t nq, const float* qdev /*(nq,ld)*/, int k, float* Ddev, int64_t* Idev,
                        int64_t id_offset, hipStream_t s) {
     const RowStore& R = h->rows;
+    if (R.dtype == SSMI_F16 && (R.ld % 64) == 0 && nq >= mfma_min_batch())
+        return flat_search_mfma(h, nq, qdev, k, Ddev, Idev, id_offset, s);
     ScanPlan p;
     std::string err;
     // bound the partial-list buffer: process queries in batches

@@ -21,6 +21,17 @@ bool plan_flat_scan(int dtype, int ld, long long nrows, int nq, int k, int num_c
 hipError_t launch_flat_scan_f32(const RowView& X, const float* Q, int nq, int k, skey_t* partial, const ScanPlan& p, hipStream_t s);
 hipError_t launch_flat_scan_f16(const RowView& X, const float* Q, int nq, int k, skey_t* partial, const ScanPlan& p, hipStream_t s);
 
+// K2 planning + launch (fp16 storage, ld % 64 == 0)
+struct MfmaPlan {
+    int nqt, nslices, grid;
+    long long rows_per_slice;
+    size_t qh_bytes, cand_bytes, lds;
+};
+bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_cu, MfmaPlan* p);
+// Q: (nq, ld) fp32 on device; qh/cand: workspaces of p.qh_bytes / p.cand_bytes; partial: [nq][p.nslices][k]
+hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, const MfmaPlan& p, void* qh, void* cand,
+                            skey_t* partial, hipStream_t s);
+
 // K3: merge P sorted k-lists of keys per query -> (D, I)
 hipError_t launch_merge_keys(const skey_t* partial, int nq, int P, int k, float* D, int64_t* I,
                              int64_t id_offset, hipStream_t s);
