@@ -145,6 +145,8 @@ int ssmi_index_get_timing(const ssmi_index* h, ssmi_timing* out);
 int ssmi_index_get_scan_times(const ssmi_index* h, int max_n, float* ms_out, int* n_out);
 /* IVF introspection for tests: list sizes (nlist int64) */
 int ssmi_index_get_list_sizes(const ssmi_index* h, int64_t* out_host);
+/* ... and the list each stored vector was assigned to (ntotal int32, indexed by id) */
+int ssmi_index_get_assignments(const ssmi_index* h, int32_t* out_host);
 
 #ifdef __cplusplus
 }

@@ -28,30 +28,6 @@ int fail(const char* fmt, ...) {
 }
 }  // namespace ssmi
 
-#define HIPCHECK(expr)                                                                             \
-    do {                                                                                           \
-        hipError_t e__ = (expr);                                                                   \
-        if (e__ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
-    } while (0)
-#define CHECK(expr)        \
-    do {                   \
-        int rc__ = (expr); \
-        if (rc__) return rc__; \
-    } while (0)
-
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
-    }
-    ~DeviceGuard() {
-        int cur = -1;
-        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
-    }
-};
-
 // ---------------------------------------------------------------------------
 // RowStore
 // ---------------------------------------------------------------------------
@@ -268,8 +244,10 @@ int ssmi_index_set_nprobe(ssmi_index* h, int nprobe) {
 }
 
 // --------------------------------------------------------------------- add
-static int flat_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind) {
-    RowStore& R = h->rows;
+}  // extern "C" (reopened below)
+namespace ssmi {
+// Append n rows (host or device, fp32 or fp16) to a row store, converting/padding as needed.
+int store_add(ssmi_index* h, RowStore& R, int64_t n, const void* x, int src_dtype, int mem_kind) {
     const long long row0 = R.nrows;
     if ((unsigned long long)(row0 + n) >= 0xFFFFFFFFull) return fail("index would exceed 2^32-2 vectors");
     CHECK(R.reserve(row0 + n, h->stream));
@@ -308,6 +286,8 @@ static int flat_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int 
     R.nrows = row0 + n;
     return 0;
 }
+}  // namespace ssmi
+extern "C" {
 
 int ssmi_index_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind) {
     if (!h) return fail("NULL index");
@@ -317,7 +297,7 @@ int ssmi_index_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int m
     if (src_dtype != SSMI_F32 && src_dtype != SSMI_F16) return fail("unknown source dtype %d", src_dtype);
     if (mem_kind != SSMI_HOST && mem_kind != SSMI_DEVICE) return fail("unknown mem_kind %d", mem_kind);
     DeviceGuard g(h->device);
-    if (h->kind == SSMI_KIND_FLAT) return flat_add(h, n, x, src_dtype, mem_kind);
+    if (h->kind == SSMI_KIND_FLAT) return store_add(h, h->rows, n, x, src_dtype, mem_kind);
     return ivf_add(h, n, x, src_dtype, mem_kind);
 }
 
@@ -351,9 +331,8 @@ static int mfma_min_batch() {
     return v < 1 ? 1 : v;
 }
 
-static int flat_search_mfma(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev, int64_t* Idev,
-                            int64_t id_offset, hipStream_t s) {
-    const RowStore& R = h->rows;
+static int store_search_mfma(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev, int k, float* Ddev,
+                             int64_t* Idev, int64_t id_offset, hipStream_t s, bool record) {
     const int64_t kMaxBatch = 4096;  // 16 query tiles -> 16 database slices on 256 CUs
     hipEvent_t* ev = h->ev[h->n_searches % ssmi_index::kEvRing];
     MfmaPlan p = {};
@@ -364,13 +343,14 @@ static int flat_search_mfma(ssmi_index* h, int64_t nq, const float* qdev, int k,
         CHECK(ensure_ws(h, 5, p.cand_bytes));
         CHECK(ensure_ws(h, 2, (size_t)nb * p.nslices * k * sizeof(skey_t)));
         skey_t* partial = (skey_t*)h->ws[2];
-        if (done == 0) HIPCHECK(hipEventRecord(ev[0], s));
+        if (record && done == 0) HIPCHECK(hipEventRecord(ev[0], s));
         HIPCHECK(launch_flat_mfma(R.view(), qdev + (size_t)done * R.ld, nb, k, p, h->ws[4], h->ws[5], partial, s));
-        if (done == 0) HIPCHECK(hipEventRecord(ev[1], s));
+        if (record && done == 0) HIPCHECK(hipEventRecord(ev[1], s));
         HIPCHECK(launch_merge_keys(partial, nb, p.nslices, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
                                    id_offset, s));
-        if (done == 0) HIPCHECK(hipEventRecord(ev[2], s));
+        if (record && done == 0) HIPCHECK(hipEventRecord(ev[2], s));
     }
+    if (!record) return 0;
     h->n_searches++;
     h->timing_valid = true;
     h->timing.last_path = 1;
@@ -380,11 +360,15 @@ static int flat_search_mfma(ssmi_index* h, int64_t nq, const float* qdev, int k,
     return 0;
 }
 
-static int flat_search(ssmi_index* h, int64_t nq, const float* qdev /*(nq,ld)*/, int k, float* Ddev, int64_t* Idev,
-                       int64_t id_offset, hipStream_t s) {
-    const RowStore& R = h->rows;
+}  // extern "C" (reopened below)
+namespace ssmi {
+// Exact top-k of (nq, ld) fp32 device queries over one row store: K1 (streaming scan)
+// for small batches, K2 (MFMA) for large batches over fp16 rows; K3 merges.
+// record = false: no events/timing (used for the IVF coarse quantizer).
+int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev /*(nq,ld)*/, int k, float* Ddev,
+                 int64_t* Idev, int64_t id_offset, hipStream_t s, bool record) {
     if (R.dtype == SSMI_F16 && (R.ld % 64) == 0 && nq >= mfma_min_batch())
-        return flat_search_mfma(h, nq, qdev, k, Ddev, Idev, id_offset, s);
+        return store_search_mfma(h, R, nq, qdev, k, Ddev, Idev, id_offset, s, record);
     ScanPlan p;
     std::string err;
     // bound the partial-list buffer: process queries in batches
@@ -402,16 +386,17 @@ static int flat_search(ssmi_index* h, int64_t nq, const float* qdev /*(nq,ld)*/,
         CHECK(ensure_ws(h, 2, (size_t)nb * per_q));
         skey_t* partial = (skey_t*)h->ws[2];
         const float* qb = qdev + (size_t)done * R.ld;
-        if (first) HIPCHECK(hipEventRecord(ev[0], s));
+        if (record && first) HIPCHECK(hipEventRecord(ev[0], s));
         if (R.dtype == SSMI_F32) HIPCHECK(launch_flat_scan_f32(R.view(), qb, (int)nb, k, partial, p, s));
         else HIPCHECK(launch_flat_scan_f16(R.view(), qb, (int)nb, k, partial, p, s));
-        if (first) HIPCHECK(hipEventRecord(ev[1], s));
+        if (record && first) HIPCHECK(hipEventRecord(ev[1], s));
         HIPCHECK(launch_merge_keys(partial, (int)nb, p.grid_x, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
                                    id_offset, s));
-        if (first) HIPCHECK(hipEventRecord(ev[2], s));
+        if (record && first) HIPCHECK(hipEventRecord(ev[2], s));
         first = false;
         done += nb;
     }
+    if (!record) return 0;
     h->n_searches++;
     h->timing_valid = true;
     h->timing.last_path = 0;
@@ -420,6 +405,8 @@ static int flat_search(ssmi_index* h, int64_t nq, const float* qdev /*(nq,ld)*/,
     h->timing.last_scan_flops = 2ll * nq * R.nrows * R.d;
     return 0;
 }
+}  // namespace ssmi
+extern "C" {
 
 int ssmi_index_search(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind, int k, float* D, int64_t* I,
                       int out_mem_kind, int64_t id_offset, void* stream) {
@@ -453,7 +440,7 @@ int ssmi_index_search(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind,
     } else {
         const float* qdev = nullptr;
         CHECK(stage_queries(h, nq, q, q_mem_kind, s, &qdev));
-        if (h->kind == SSMI_KIND_FLAT) CHECK(flat_search(h, nq, qdev, k, Ddev, Idev, id_offset, s));
+        if (h->kind == SSMI_KIND_FLAT) CHECK(store_search(h, h->rows, nq, qdev, k, Ddev, Idev, id_offset, s, true));
         else CHECK(ivf_search(h, nq, qdev, k, Ddev, Idev, id_offset, s));
     }
     if (out_mem_kind == SSMI_HOST) {

@@ -8,7 +8,7 @@
 namespace ssmi {
 
 static const int kMaxSegs = 4096;
-static const int kWsSlots = 8;
+static const int kWsSlots = 16;
 
 int fail(const char* fmt, ...);
 
@@ -54,11 +54,40 @@ struct ssmi_index {
     void* ivf = nullptr;           // ssmi::IvfState*
 };
 
+#define HIPCHECK(expr)                                                                             \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+#define CHECK(expr)        \
+    do {                   \
+        int rc__ = (expr); \
+        if (rc__) return rc__; \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+
 namespace ssmi {
+int store_add(ssmi_index* h, RowStore& R, int64_t n, const void* x, int src_dtype, int mem_kind);
 // grow-only device workspace slots (0: staging, 1: queries, 2: partial lists, 3: host-output staging, 4+: IVF)
 int ensure_ws(ssmi_index* h, int slot, size_t bytes);
 // query staging shared by the flat and IVF paths: returns (nq, ld) fp32 on device
 int stage_queries(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind, hipStream_t s, const float** out);
+
+int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev, int k, float* Ddev, int64_t* Idev,
+                 int64_t id_offset, hipStream_t s, bool record);
 
 // IVF entry points (ivf.hip)
 int ivf_create(ssmi_index* h, int nlist);

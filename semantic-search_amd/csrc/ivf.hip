@@ -1,21 +1,743 @@
-// ivf.hip - IVF-Flat (placeholder until the list kernels land in this round).
+// ivf.hip - IVF-Flat on MI355X: coarse quantizer, paged inverted lists, probe
+// planning (prefix sum) and the bucketed list scan with fused top-k (K5-K8).
+//
+// Stands behind faiss.IndexIVFFlat(IndexFlatIP(d), d, nlist, METRIC_INNER_PRODUCT)
+// as the reference builds it (core/index_factory.py:142-146) and drives it
+// (train: core/index_factory.py:191; add: core/index_manager.py:299,319;
+// search: core/index_manager.py:371).  Semantics restated from FAISS docs
+// [FAISS-lib]: k-means centroids (plain means, inner-product assignment), a
+// vector goes to the list of its max-inner-product centroid, a search visits the
+// nprobe best lists and ranks their members by exact inner product.
+//
+// Layout in HBM
+//   centroids   two small row stores (fp32 for exact small-batch assignment via
+//               K1, fp16 for large batches via the MFMA kernel K2)
+//   list rows   one slot store (`h->rows`) cut into pages of 32 slots; a list is
+//               a host-side vector of page numbers (mirrored to the device as a
+//               CSR), so appending never moves existing vectors
+//   slot_ids    uint32 id of the vector in each slot
+// Search
+//   coarse top-nprobe (K1/K2 + K3)  ->  ivf_plan_kernel: per query, exclusive
+//   prefix sum of the probed lists' sizes  ->  ivf_scan_topk_kernel: the probed
+//   rows of a query form one virtual range [0, T) that is split evenly over all
+//   waves of the grid (row granular, so short and long lists balance); each wave
+//   maps its sub-range back to (list, page, slot) and runs the same
+//   coalesced-row / register-top-k loop as K1  ->  K3 merge.
 #include "index.h"
 #include "kernels.h"
+#include "scan_impl.h"
+
+#include <algorithm>
+#include <numeric>
+#include <random>
+
+using namespace ssmi;
+
 namespace ssmi {
-int ivf_create(ssmi_index*, int) { return fail("IVF-Flat is not built yet"); }
-void ivf_destroy(ssmi_index*) {}
-int ivf_train(ssmi_index*, int64_t, const float*, int) { return fail("IVF-Flat is not built yet"); }
-int ivf_add(ssmi_index*, int64_t, const void*, int, int) { return fail("IVF-Flat is not built yet"); }
-int ivf_add_random_unit(ssmi_index*, int64_t, uint64_t) { return fail("IVF-Flat is not built yet"); }
-int ivf_search(ssmi_index*, int64_t, const float*, int, float*, int64_t*, int64_t, hipStream_t) { return fail("IVF-Flat is not built yet"); }
-int ivf_ids_to_slots(ssmi_index*, int64_t, const int64_t*, std::vector<int64_t>*) { return fail("IVF-Flat is not built yet"); }
-}  // namespace ssmi
-extern "C" {
-int ssmi_index_create_ivfflat(int, int, int, int, ssmi_index** out) { if (out) *out = nullptr; return ssmi::fail("IVF-Flat is not built yet"); }
-int ssmi_index_set_centroids(ssmi_index*, const float*, int) { return ssmi::fail("IVF-Flat is not built yet"); }
-int ssmi_index_get_centroids(const ssmi_index*, float*) { return ssmi::fail("IVF-Flat is not built yet"); }
-int ssmi_index_make_direct_map(ssmi_index*) { return ssmi::fail("IVF-Flat is not built yet"); }
-int ssmi_index_get_list_sizes(const ssmi_index*, int64_t*) { return ssmi::fail("IVF-Flat is not built yet"); }
-int ssmi_index_write(ssmi_index*, const char*) { return ssmi::fail("persistence is not built yet"); }
-int ssmi_index_read(const char*, int, int, ssmi_index** out) { if (out) *out = nullptr; return ssmi::fail("persistence is not built yet"); }
+
+static const int kPageRows = 32;
+static const int kPageShift = 5;
+
+struct IvfState {
+    RowStore cent32, cent16;
+    std::vector<std::vector<int>> pages;  // per list: page numbers in order
+    std::vector<long long> size;          // per list: vectors stored
+    long long npages = 0;
+    uint32_t* d_slot_ids = nullptr;
+    long long slot_cap = 0;
+    int* d_page_off = nullptr;  // nlist + 1
+    int* d_size = nullptr;      // nlist
+    int* d_pages = nullptr;     // npages (CSR payload)
+    long long d_pages_cap = 0;
+    bool csr_dirty = true;
+    bool has_direct_map = false;
+    std::vector<int64_t> direct_map;  // id -> slot
+    int niter = 10;                   // [FAISS-lib] ClusteringParameters default for the IVF quantizer
+    int max_points_per_centroid = 256;
+    uint64_t seed = 1234;
+};
+
+static IvfState* st(ssmi_index* h) { return reinterpret_cast<IvfState*>(h->ivf); }
+static const IvfState* st(const ssmi_index* h) { return reinterpret_cast<const IvfState*>(h->ivf); }
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+
+// (n,d) rows of S -> (n,ld) fp32 with zero tail
+template <typename S>
+__global__ void rows_to_f32_kernel(const S* __restrict__ src, int d, int ld, float* __restrict__ out) {
+    const size_t i = blockIdx.x;
+    for (int e = threadIdx.x; e < ld; e += blockDim.x) out[i * ld + e] = (e < d) ? (float)src[i * d + e] : 0.f;
 }
+
+// rows (n,ld) fp32 -> slot store rows dst_slot[i]; records the id of each slot
+template <typename T>
+__global__ void scatter_rows_kernel(const float* __restrict__ src, int ld, const int* __restrict__ dst_slot,
+                                    void* const* segs, int seg_shift, uint32_t* __restrict__ slot_ids, uint32_t id0) {
+    const size_t i = blockIdx.x;
+    const long long slot = dst_slot[i];
+    const long long mask = (1ll << seg_shift) - 1;
+    T* dst = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(segs[slot >> seg_shift]) +
+                                  (size_t)(slot & mask) * (size_t)ld * sizeof(T));
+    for (int e = threadIdx.x; e < ld; e += blockDim.x) dst[e] = (T)src[i * ld + e];
+    if (threadIdx.x == 0) slot_ids[slot] = id0 + (uint32_t)i;
+}
+
+// K6: centroid l = mean of its members (fixed summation order -> deterministic)
+__global__ void centroid_update_kernel(const float* __restrict__ X, int ld, const int* __restrict__ perm,
+                                       const int* __restrict__ off, void* const* segs32, int shift32,
+                                       void* const* segs16, int shift16) {
+    const int l = blockIdx.x;
+    const int b = off[l], e = off[l + 1];
+    if (e == b) return;  // empty cluster: handled on the host by splitting a big one
+    float* c32 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(segs32[l >> shift32]) +
+                                          (size_t)(l & ((1 << shift32) - 1)) * (size_t)ld * 4);
+    __half* c16 = reinterpret_cast<__half*>(reinterpret_cast<unsigned char*>(segs16[l >> shift16]) +
+                                            (size_t)(l & ((1 << shift16) - 1)) * (size_t)ld * 2);
+    const float inv = 1.0f / (float)(e - b);
+    for (int x = threadIdx.x; x < ld; x += blockDim.x) {
+        float acc = 0.f;
+        for (int i = b; i < e; ++i) acc += X[(size_t)perm[i] * ld + x];
+        acc *= inv;
+        c32[x] = acc;
+        c16[x] = __float2half(acc);
+    }
+}
+
+// [FAISS-lib] empty-cluster fix: copy a populated centroid and nudge the pair apart
+__global__ void split_centroid_kernel(int ld, void* const* segs32, int shift32, void* const* segs16, int shift16,
+                                      int dst, int src, float eps) {
+    float* s32 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(segs32[src >> shift32]) +
+                                          (size_t)(src & ((1 << shift32) - 1)) * (size_t)ld * 4);
+    float* d32 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(segs32[dst >> shift32]) +
+                                          (size_t)(dst & ((1 << shift32) - 1)) * (size_t)ld * 4);
+    __half* s16 = reinterpret_cast<__half*>(reinterpret_cast<unsigned char*>(segs16[src >> shift16]) +
+                                            (size_t)(src & ((1 << shift16) - 1)) * (size_t)ld * 2);
+    __half* d16 = reinterpret_cast<__half*>(reinterpret_cast<unsigned char*>(segs16[dst >> shift16]) +
+                                            (size_t)(dst & ((1 << shift16) - 1)) * (size_t)ld * 2);
+    for (int x = threadIdx.x; x < ld; x += blockDim.x) {
+        const float v = s32[x];
+        const float a = (x & 1) ? v * (1.f + eps) : v * (1.f - eps);
+        const float b = (x & 1) ? v * (1.f - eps) : v * (1.f + eps);
+        d32[x] = a; d16[x] = __float2half(a);
+        s32[x] = b; s16[x] = __float2half(b);
+    }
+}
+
+// K7 (search side): per query, exclusive prefix sum of the probed lists' sizes.
+// prefix: (nq, nprobe+1) int64; one 256-thread block per query.
+__global__ void ivf_plan_kernel(const int64_t* __restrict__ Ic, int nprobe, const int* __restrict__ list_size,
+                                long long* __restrict__ prefix) {
+    __shared__ long long wsum[4];
+    __shared__ long long carry;
+    const int q = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t* ic = Ic + (size_t)q * nprobe;
+    long long* pf = prefix + (size_t)q * (nprobe + 1);
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nprobe; base += 256) {
+        const int j = base + threadIdx.x;
+        long long v = 0;
+        if (j < nprobe) { const int64_t l = ic[j]; v = (l >= 0) ? (long long)list_size[l] : 0; }
+        long long incl = v;  // inclusive scan inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long up = (long long)shfl_up64((skey_t)incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        long long woff = carry;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        if (j < nprobe) pf[j] = woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry = woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) pf[nprobe] = carry;
+}
+
+struct IvfScanParams {
+    RowView X;  // slot store
+    const float* Q;             // (nq, ld) fp32
+    const int64_t* Ic;          // (nq, nprobe) probed lists, best first
+    const long long* prefix;    // (nq, nprobe+1)
+    const int* page_off;        // nlist+1
+    const int* pages;           // CSR payload
+    const uint32_t* slot_ids;
+    int nprobe, k;
+    skey_t* partial;            // [nq][gridDim.x][k]
+};
+
+// K8: bucketed list scan with fused per-wavefront top-k.  grid = (gx, nq), 4 waves.
+template <typename T, int R>
+__global__ void __launch_bounds__(256) ivf_scan_topk_kernel(IvfScanParams P) {
+    constexpr int V = ElemTraits<T>::V;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* qs = reinterpret_cast<float*>(smem);
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int q = blockIdx.y;
+    const int ld = P.X.ld;
+    const int nch = (ld + 64 * V - 1) / (64 * V);
+    const int ldq = nch * 64 * V;
+    const int row_bytes = ld * (int)sizeof(T);
+    for (int e = threadIdx.x; e < ldq; e += blockDim.x)
+        qs[q_lds_index<V>(e)] = (e < ld) ? P.Q[(size_t)q * ld + e] : 0.f;
+    __syncthreads();
+
+    const long long* pf = P.prefix + (size_t)q * (P.nprobe + 1);
+    const int64_t* ic = P.Ic + (size_t)q * P.nprobe;
+    const long long total = pf[P.nprobe];
+    const long long nw = (long long)gridDim.x * 4, wv = (long long)blockIdx.x * 4 + wave;
+    long long r = total * wv / nw;
+    const long long r_hi = total * (wv + 1) / nw;
+    const long long seg_mask = (1ll << P.X.seg_shift) - 1;
+
+    WaveTopK<R> top;
+    top.init();
+    skey_t thr = 0;
+    float thr_s = SSMI_NEG_MAX;
+
+    if (r < r_hi) {
+        int lo = 0, hi = P.nprobe - 1;  // last j with pf[j] <= r
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (pf[mid] <= r) lo = mid; else hi = mid - 1;
+        }
+        int j = lo;
+        while (r < r_hi) {
+            while (pf[j + 1] <= r) ++j;
+            const long long base = pf[j];
+            const long long lend = pf[j + 1] < r_hi ? pf[j + 1] : r_hi;
+            const int* lp = P.pages + P.page_off[ic[j]];
+            for (; r < lend; ++r) {
+                const long long o = r - base;
+                const long long slot = (long long)lp[o >> kPageShift] * kPageRows + (o & (kPageRows - 1));
+                const unsigned char* rowp = reinterpret_cast<const unsigned char*>(P.X.segs[slot >> P.X.seg_shift]) +
+                                            (size_t)(slot & seg_mask) * (size_t)row_bytes;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                constexpr int G = 8;
+#pragma unroll 1
+                for (int c0 = 0; c0 < nch; c0 += G) {
+                    uint4 x[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const int off = ((c0 + g) * 64 + lane) * 16;
+                        x[g] = make_uint4(0, 0, 0, 0);
+                        if (off < row_bytes) x[g] = load16_nt(rowp + off);
+                    }
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        if (c0 + g < nch) {
+                            float xf[V];
+                            Unpack<T>::run(x[g], xf);
+#pragma unroll
+                            for (int p = 0; p < V / 4; ++p) {
+                                const float4 t4 = *reinterpret_cast<const float4*>(qs + (c0 + g) * 64 * V + p * 256 + lane * 4);
+                                a0 = fmaf(xf[4 * p], t4.x, a0);
+                                a1 = fmaf(xf[4 * p + 1], t4.y, a1);
+                                a2 = fmaf(xf[4 * p + 2], t4.z, a2);
+                                a3 = fmaf(xf[4 * p + 3], t4.w, a3);
+                            }
+                        }
+                    }
+                }
+                float s = wave_sum((a0 + a1) + (a2 + a3));
+                s = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s)));
+                if (s >= thr_s) {  // cheap float gate; the exact (score, id) order needs the id
+                    const skey_t key = make_key(s, P.slot_ids[slot]);
+                    if (key > thr) {
+                        top.insert(key);
+                        thr = top.kth(P.k);
+                        thr_s = (thr == 0) ? SSMI_NEG_MAX : key_score(thr);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    skey_t* lds_keys = reinterpret_cast<skey_t*>(smem);
+    block_merge<R>(top, lds_keys, wave, 4);
+    if (wave == 0) top.store(P.partial + ((size_t)q * gridDim.x + blockIdx.x) * P.k, P.k);
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+
+int ivf_create(ssmi_index* h, int nlist) {
+    if (nlist < 1 || nlist > (1 << 24)) return fail("nlist %d out of range [1, 2^24]", nlist);
+    IvfState* S = new IvfState();
+    h->ivf = S;
+    h->nlist = nlist;
+    h->nprobe = 1;  // FAISS default
+    h->trained = false;
+    if (S->cent32.init(h->rows.d, SSMI_F32)) return 1;
+    if (S->cent16.init(h->rows.d, SSMI_F16)) return 1;
+    S->pages.assign(nlist, {});
+    S->size.assign(nlist, 0);
+    HIPCHECK(hipMalloc((void**)&S->d_page_off, sizeof(int) * (nlist + 1)));
+    HIPCHECK(hipMalloc((void**)&S->d_size, sizeof(int) * nlist));
+    HIPCHECK(hipMemset(S->d_page_off, 0, sizeof(int) * (nlist + 1)));
+    HIPCHECK(hipMemset(S->d_size, 0, sizeof(int) * nlist));
+    return 0;
+}
+
+void ivf_destroy(ssmi_index* h) {
+    IvfState* S = st(h);
+    if (!S) return;
+    S->cent32.destroy();
+    S->cent16.destroy();
+    if (S->d_slot_ids) (void)hipFree(S->d_slot_ids);
+    if (S->d_page_off) (void)hipFree(S->d_page_off);
+    if (S->d_size) (void)hipFree(S->d_size);
+    if (S->d_pages) (void)hipFree(S->d_pages);
+    delete S;
+    h->ivf = nullptr;
+}
+
+// (n,d) rows of src_dtype, host or device -> (n, ld) fp32 on the device (workspace slot 8 when a copy is needed)
+static int rows_to_device_f32(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind, const float** out) {
+    const RowStore& R = h->rows;
+    if (mem_kind == SSMI_DEVICE && src_dtype == SSMI_F32 && R.ld == R.d) { *out = (const float*)x; return 0; }
+    CHECK(ensure_ws(h, 8, (size_t)n * R.ld * 4));
+    float* dst = (float*)h->ws[8];
+    if (src_dtype == SSMI_F32 && R.ld == R.d) {
+        HIPCHECK(hipMemcpyAsync(dst, x, (size_t)n * R.d * 4, hipMemcpyHostToDevice, h->stream));
+        *out = dst;
+        return 0;
+    }
+    const size_t el = src_dtype == SSMI_F32 ? 4 : 2;
+    const void* src = x;
+    if (mem_kind == SSMI_HOST) {
+        CHECK(ensure_ws(h, 0, (size_t)n * R.d * el));
+        HIPCHECK(hipMemcpyAsync(h->ws[0], x, (size_t)n * R.d * el, hipMemcpyHostToDevice, h->stream));
+        src = h->ws[0];
+    }
+    if (src_dtype == SSMI_F32)
+        hipLaunchKernelGGL((rows_to_f32_kernel<float>), dim3((unsigned)n), dim3(256), 0, h->stream, (const float*)src, R.d, R.ld, dst);
+    else
+        hipLaunchKernelGGL((rows_to_f32_kernel<__half>), dim3((unsigned)n), dim3(256), 0, h->stream, (const __half*)src, R.d, R.ld, dst);
+    HIPCHECK(hipGetLastError());
+    *out = dst;
+    return 0;
+}
+
+// nearest centroid (max inner product) of n device rows -> host labels
+static int assign_to_centroids(ssmi_index* h, int64_t n, const float* xdev, std::vector<int>* labels) {
+    IvfState* S = st(h);
+    const RowStore& C = (n >= 9 && (S->cent16.ld % 64) == 0) ? S->cent16 : S->cent32;
+    CHECK(ensure_ws(h, 6, (size_t)n * 4));
+    CHECK(ensure_ws(h, 7, (size_t)n * 8));
+    CHECK(store_search(h, C, n, xdev, 1, (float*)h->ws[6], (int64_t*)h->ws[7], 0, h->stream, false));
+    std::vector<int64_t> tmp((size_t)n);
+    HIPCHECK(hipMemcpyAsync(tmp.data(), h->ws[7], (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    labels->resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (tmp[i] < 0 || tmp[i] >= h->nlist) return fail("internal: centroid assignment produced list %lld", (long long)tmp[i]);
+        (*labels)[i] = (int)tmp[i];
+    }
+    return 0;
+}
+
+static int install_centroids(ssmi_index* h, const float* c, int mem_kind) {
+    IvfState* S = st(h);
+    S->cent32.nrows = 0;
+    S->cent16.nrows = 0;
+    CHECK(store_add(h, S->cent32, h->nlist, c, SSMI_F32, mem_kind));
+    CHECK(store_add(h, S->cent16, h->nlist, c, SSMI_F32, mem_kind));
+    h->trained = true;
+    return 0;
+}
+
+int ivf_train(ssmi_index* h, int64_t n, const float* x, int mem_kind) {
+    IvfState* S = st(h);
+    if (h->trained) return 0;  // like FAISS: training a trained index is a no-op
+    if (n < 1 || !x) return fail("train: no training vectors");
+    const int nlist = h->nlist;
+    if (n < nlist) return fail("train: number of training points (%lld) should be at least as large as number of clusters (%d)", (long long)n, nlist);
+    const RowStore& R = h->rows;
+    const int d = R.d, ld = R.ld;
+    std::mt19937_64 rng(S->seed);
+
+    // [FAISS-lib] subsample to at most max_points_per_centroid * nlist training points
+    int64_t nt = n;
+    std::vector<int64_t> pick;
+    const int64_t cap = (int64_t)S->max_points_per_centroid * nlist;
+    if (n > cap) {
+        pick.resize((size_t)n);
+        std::iota(pick.begin(), pick.end(), (int64_t)0);
+        for (int64_t i = 0; i < cap; ++i) std::swap(pick[i], pick[i + (int64_t)(rng() % (uint64_t)(n - i))]);
+        pick.resize((size_t)cap);
+        std::sort(pick.begin(), pick.end());
+        nt = cap;
+    }
+    // training set as (nt, ld) fp32 on the device (own allocation: it outlives workspace reuse)
+    float* X = nullptr;
+    HIPCHECK(hipMalloc((void**)&X, (size_t)nt * ld * 4));
+    struct Free { float* p; ~Free() { if (p) (void)hipFree(p); } } freeX{X};
+    if (ld != d) HIPCHECK(hipMemsetAsync(X, 0, (size_t)nt * ld * 4, h->stream));
+    const hipMemcpyKind kind = mem_kind == SSMI_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    if (pick.empty()) {
+        HIPCHECK(hipMemcpy2DAsync(X, (size_t)ld * 4, x, (size_t)d * 4, (size_t)d * 4, (size_t)nt, kind, h->stream));
+    } else {
+        for (int64_t i = 0; i < nt;) {  // runs of consecutive picks copy together
+            int64_t j = i + 1;
+            while (j < nt && pick[j] == pick[j - 1] + 1) ++j;
+            HIPCHECK(hipMemcpy2DAsync(X + (size_t)i * ld, (size_t)ld * 4, x + (size_t)pick[i] * d, (size_t)d * 4,
+                                      (size_t)d * 4, (size_t)(j - i), kind, h->stream));
+            i = j;
+        }
+    }
+    HIPCHECK(hipStreamSynchronize(h->stream));
+
+    // initial centroids: nlist distinct random training points
+    std::vector<int64_t> perm((size_t)nt);
+    std::iota(perm.begin(), perm.end(), (int64_t)0);
+    for (int i = 0; i < nlist; ++i) std::swap(perm[i], perm[i + (int64_t)(rng() % (uint64_t)(nt - i))]);
+    float* C0 = nullptr;
+    HIPCHECK(hipMalloc((void**)&C0, (size_t)nlist * d * 4));
+    struct Free2 { float* p; ~Free2() { if (p) (void)hipFree(p); } } freeC{C0};
+    for (int i = 0; i < nlist; ++i)
+        HIPCHECK(hipMemcpyAsync(C0 + (size_t)i * d, X + (size_t)perm[i] * ld, (size_t)d * 4, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    CHECK(install_centroids(h, C0, SSMI_DEVICE));
+    h->trained = false;
+
+    int *d_perm = nullptr, *d_off = nullptr;
+    HIPCHECK(hipMalloc((void**)&d_perm, (size_t)nt * 4));
+    struct Free3 { int* p; ~Free3() { if (p) (void)hipFree(p); } } freeP{d_perm};
+    HIPCHECK(hipMalloc((void**)&d_off, (size_t)(nlist + 1) * 4));
+    struct Free4 { int* p; ~Free4() { if (p) (void)hipFree(p); } } freeO{d_off};
+
+    std::vector<int> labels, off((size_t)nlist + 1), order((size_t)nt), cursor((size_t)nlist);
+    for (int it = 0; it < S->niter; ++it) {
+        // K5: assignment = nearest (max inner product) centroid, in chunks that bound the query workspace
+        labels.clear();
+        std::vector<int> part;
+        const int64_t chunk = 1 << 16;
+        for (int64_t b = 0; b < nt; b += chunk) {
+            const int64_t cnt = std::min(chunk, nt - b);
+            CHECK(assign_to_centroids(h, cnt, X + (size_t)b * ld, &part));
+            labels.insert(labels.end(), part.begin(), part.end());
+        }
+        // counting sort of the points by label (stable -> fixed summation order)
+        std::fill(off.begin(), off.end(), 0);
+        for (int64_t i = 0; i < nt; ++i) off[labels[i] + 1]++;
+        for (int l = 0; l < nlist; ++l) off[l + 1] += off[l];
+        std::copy(off.begin(), off.end() - 1, cursor.begin());
+        for (int64_t i = 0; i < nt; ++i) order[cursor[labels[i]]++] = (int)i;
+        HIPCHECK(hipMemcpyAsync(d_perm, order.data(), (size_t)nt * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(hipMemcpyAsync(d_off, off.data(), (size_t)(nlist + 1) * 4, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(centroid_update_kernel, dim3(nlist), dim3(256), 0, h->stream, X, ld, d_perm, d_off,
+                           (void* const*)S->cent32.d_segs, S->cent32.seg_shift, (void* const*)S->cent16.d_segs,
+                           S->cent16.seg_shift);
+        HIPCHECK(hipGetLastError());
+        // empty clusters: split the currently largest cluster (deterministic variant of FAISS' fix)
+        std::vector<int> count((size_t)nlist);
+        for (int l = 0; l < nlist; ++l) count[l] = off[l + 1] - off[l];
+        for (int l = 0; l < nlist; ++l) {
+            if (count[l] != 0) continue;
+            const int big = (int)(std::max_element(count.begin(), count.end()) - count.begin());
+            if (count[big] < 2) break;
+            hipLaunchKernelGGL(split_centroid_kernel, dim3(1), dim3(256), 0, h->stream, ld, (void* const*)S->cent32.d_segs,
+                               S->cent32.seg_shift, (void* const*)S->cent16.d_segs, S->cent16.seg_shift, l, big,
+                               1.0f / 1024.0f);
+            HIPCHECK(hipGetLastError());
+            count[l] = count[big] / 2;
+            count[big] -= count[l];
+        }
+        HIPCHECK(hipStreamSynchronize(h->stream));
+    }
+    h->trained = true;
+    return 0;
+}
+
+static int sync_csr(ssmi_index* h) {
+    IvfState* S = st(h);
+    if (!S->csr_dirty) return 0;
+    const int nlist = h->nlist;
+    std::vector<int> off((size_t)nlist + 1, 0), sz((size_t)nlist), flat;
+    flat.reserve((size_t)S->npages);
+    for (int l = 0; l < nlist; ++l) {
+        off[l] = (int)flat.size();
+        flat.insert(flat.end(), S->pages[l].begin(), S->pages[l].end());
+        sz[l] = (int)S->size[l];
+    }
+    off[nlist] = (int)flat.size();
+    if ((long long)flat.size() > S->d_pages_cap) {
+        HIPCHECK(hipDeviceSynchronize());
+        if (S->d_pages) HIPCHECK(hipFree(S->d_pages));
+        S->d_pages_cap = std::max<long long>(1024, (long long)flat.size() * 2);
+        HIPCHECK(hipMalloc((void**)&S->d_pages, (size_t)S->d_pages_cap * 4));
+    }
+    HIPCHECK(hipMemcpyAsync(S->d_page_off, off.data(), (size_t)(nlist + 1) * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipMemcpyAsync(S->d_size, sz.data(), (size_t)nlist * 4, hipMemcpyHostToDevice, h->stream));
+    if (!flat.empty())
+        HIPCHECK(hipMemcpyAsync(S->d_pages, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    S->csr_dirty = false;
+    return 0;
+}
+
+static int ensure_slots(ssmi_index* h, long long npages) {
+    IvfState* S = st(h);
+    const long long slots = npages * kPageRows;
+    CHECK(h->rows.reserve(slots, h->stream));
+    if (slots > S->slot_cap) {
+        long long cap = std::max<long long>(4096, S->slot_cap);
+        while (cap < slots) cap *= 2;
+        uint32_t* p = nullptr;
+        HIPCHECK(hipMalloc((void**)&p, (size_t)cap * 4));
+        HIPCHECK(hipMemsetAsync(p, 0xff, (size_t)cap * 4, h->stream));
+        if (S->d_slot_ids) {
+            HIPCHECK(hipMemcpyAsync(p, S->d_slot_ids, (size_t)S->slot_cap * 4, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHECK(hipDeviceSynchronize());
+            HIPCHECK(hipFree(S->d_slot_ids));
+        }
+        S->d_slot_ids = p;
+        S->slot_cap = cap;
+    }
+    h->rows.nrows = slots;
+    h->ivf_slots_used = slots;
+    return 0;
+}
+
+// place vectors (already on the device as (n, ld) fp32) into their lists
+static int ivf_add_device_f32(ssmi_index* h, int64_t n, const float* xdev) {
+    IvfState* S = st(h);
+    std::vector<int> labels;
+    CHECK(assign_to_centroids(h, n, xdev, &labels));
+    std::vector<int> dst((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const int l = labels[i];
+        const long long pos = S->size[l];
+        if ((pos & (kPageRows - 1)) == 0) S->pages[l].push_back((int)S->npages++);
+        const long long slot = (long long)S->pages[l][pos >> kPageShift] * kPageRows + (pos & (kPageRows - 1));
+        dst[i] = (int)slot;
+        S->size[l] = pos + 1;
+        if (S->has_direct_map) S->direct_map.push_back(slot);
+    }
+    if (S->npages * kPageRows >= (1ll << 31)) return fail("IVF slot store would exceed 2^31 slots");
+    CHECK(ensure_slots(h, S->npages));
+    CHECK(ensure_ws(h, 9, (size_t)n * 4));
+    HIPCHECK(hipMemcpyAsync(h->ws[9], dst.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    const RowStore& R = h->rows;
+    if (R.dtype == SSMI_F32)
+        hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)h->ws[9],
+                           (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, (uint32_t)h->ivf_ntotal);
+    else
+        hipLaunchKernelGGL((scatter_rows_kernel<__half>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)h->ws[9],
+                           (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, (uint32_t)h->ivf_ntotal);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    h->ivf_ntotal += n;
+    S->csr_dirty = true;
+    return 0;
+}
+
+int ivf_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind) {
+    if (!h->trained) return fail("add on an untrained IVF index (call train first)");
+    if ((unsigned long long)(h->ivf_ntotal + n) >= 0xFFFFFFFFull) return fail("index would exceed 2^32-2 vectors");
+    const RowStore& R = h->rows;
+    const size_t el = src_dtype == SSMI_F32 ? 4 : 2;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(1 << 16, ((size_t)1 << 30) / ((size_t)R.ld * 4)));
+    for (int64_t done = 0; done < n; done += chunk) {
+        const int64_t cnt = std::min(chunk, n - done);
+        const float* xdev = nullptr;
+        CHECK(rows_to_device_f32(h, cnt, (const char*)x + (size_t)done * R.d * el, src_dtype, mem_kind, &xdev));
+        CHECK(ivf_add_device_f32(h, cnt, xdev));
+    }
+    return 0;
+}
+
+int ivf_add_random_unit(ssmi_index* h, int64_t n, uint64_t seed) {
+    if (!h->trained) return fail("add on an untrained IVF index (call train first)");
+    // generate into a scratch flat store chunk by chunk, then route through the normal add path
+    const RowStore& R = h->rows;
+    RowStore tmp;
+    if (tmp.init(R.d, SSMI_F32)) return 1;
+    struct D { RowStore* s; ~D() { s->destroy(); } } guard{&tmp};
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(1 << 16, ((size_t)1 << 30) / ((size_t)R.ld * 4)));
+    if (chunk > (1ll << tmp.seg_shift)) return fail("internal: chunk exceeds scratch segment");
+    CHECK(tmp.reserve(std::min<int64_t>(chunk, n), h->stream));
+    for (int64_t done = 0; done < n; done += chunk) {
+        const int64_t cnt = std::min(chunk, n - done);
+        tmp.nrows = 0;
+        // rows are numbered by their final id so the data does not depend on the chunking
+        HIPCHECK(launch_fill_random_unit(tmp.view(), SSMI_F32, (void* const*)tmp.d_segs, 0, cnt, R.d, seed + 0x9E3779B97F4A7C15ull * (uint64_t)(done / chunk + 1), h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        CHECK(ivf_add_device_f32(h, cnt, (const float*)tmp.segs[0]));
+    }
+    return 0;
+}
+
+int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev, int64_t* Idev, int64_t id_offset,
+               hipStream_t s) {
+    IvfState* S = st(h);
+    const RowStore& R = h->rows;
+    CHECK(sync_csr(h));
+    const int nprobe = std::min(h->nprobe, h->nlist);
+    if (nprobe > kMaxK) return fail("nprobe=%d exceeds the supported maximum %d", nprobe, kMaxK);
+    int r = 1;
+    while (64 * r < k) r <<= 1;
+    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(1024, ((int64_t)h->num_cu * 6 + nq - 1) / nq));
+    const int V = R.dtype == SSMI_F32 ? 4 : 8;
+    const int ldq = (R.ld + 64 * V - 1) / (64 * V) * 64 * V;
+    const size_t lds = std::max((size_t)ldq * 4, (size_t)4 * 64 * r * sizeof(skey_t));
+    hipEvent_t* ev = h->ev[h->n_searches % ssmi_index::kEvRing];
+    const int64_t qbatch = std::max<int64_t>(1, std::min<int64_t>(nq, ((size_t)256 << 20) / ((size_t)gx * k * sizeof(skey_t))));
+    for (int64_t done = 0; done < nq; done += qbatch) {
+        const int nb = (int)std::min(qbatch, nq - done);
+        const float* qb = qdev + (size_t)done * R.ld;
+        // coarse quantizer: top-nprobe centroids per query
+        CHECK(ensure_ws(h, 6, (size_t)nb * nprobe * 4));
+        CHECK(ensure_ws(h, 7, (size_t)nb * nprobe * 8));
+        CHECK(ensure_ws(h, 10, (size_t)nb * (nprobe + 1) * 8));
+        const RowStore& C = (nb >= 9 && (S->cent16.ld % 64) == 0) ? S->cent16 : S->cent32;
+        CHECK(store_search(h, C, nb, qb, nprobe, (float*)h->ws[6], (int64_t*)h->ws[7], 0, s, false));
+        hipLaunchKernelGGL(ivf_plan_kernel, dim3(nb), dim3(256), 0, s, (const int64_t*)h->ws[7], nprobe, S->d_size,
+                           (long long*)h->ws[10]);
+        HIPCHECK(hipGetLastError());
+        CHECK(ensure_ws(h, 2, (size_t)nb * gx * k * sizeof(skey_t)));
+        IvfScanParams P;
+        P.X = R.view(); P.Q = qb; P.Ic = (const int64_t*)h->ws[7]; P.prefix = (const long long*)h->ws[10];
+        P.page_off = S->d_page_off; P.pages = S->d_pages; P.slot_ids = S->d_slot_ids; P.nprobe = nprobe; P.k = k;
+        P.partial = (skey_t*)h->ws[2];
+        if (done == 0) HIPCHECK(hipEventRecord(ev[0], s));
+#define IVF_LAUNCH(TT, RR)                                                                                       \
+    case RR: {                                                                                                   \
+        if (lds > 48 * 1024)                                                                                     \
+            HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_scan_topk_kernel<TT, RR>),           \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+        hipLaunchKernelGGL((ivf_scan_topk_kernel<TT, RR>), dim3(gx, nb), dim3(256), lds, s, P);                 \
+        break;                                                                                                   \
+    }
+        if (R.dtype == SSMI_F32) {
+            switch (r) { IVF_LAUNCH(float, 1) IVF_LAUNCH(float, 2) IVF_LAUNCH(float, 4) IVF_LAUNCH(float, 8) IVF_LAUNCH(float, 16) default: return fail("bad k"); }
+        } else {
+            switch (r) { IVF_LAUNCH(__half, 1) IVF_LAUNCH(__half, 2) IVF_LAUNCH(__half, 4) IVF_LAUNCH(__half, 8) IVF_LAUNCH(__half, 16) default: return fail("bad k"); }
+        }
+#undef IVF_LAUNCH
+        HIPCHECK(hipGetLastError());
+        if (done == 0) HIPCHECK(hipEventRecord(ev[1], s));
+        HIPCHECK(launch_merge_keys((const skey_t*)h->ws[2], nb, gx, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
+                                   id_offset, s));
+        if (done == 0) HIPCHECK(hipEventRecord(ev[2], s));
+    }
+    h->n_searches++;
+    h->timing_valid = true;
+    h->timing.last_path = 2;
+    h->timing.last_grid = gx;
+    h->timing.last_scan_bytes = -1;  // depends on the probed lists; see ssmi_index_get_list_sizes
+    h->timing.last_scan_flops = -1;
+    return 0;
+}
+
+int ivf_ids_to_slots(ssmi_index* h, int64_t n, const int64_t* ids, std::vector<int64_t>* slots) {
+    IvfState* S = st(h);
+    if (!S->has_direct_map) return fail("direct map not initialized (call make_direct_map first)");
+    slots->resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) (*slots)[i] = S->direct_map[(size_t)ids[i]];
+    return 0;
+}
+
+}  // namespace ssmi
+
+// ---------------------------------------------------------------------------
+// C ABI (IVF part)
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int ssmi_index_create_ivfflat(int d, int nlist, int storage_dtype, int device, ssmi_index** out) {
+    if (!out) return fail("out is NULL");
+    *out = nullptr;
+    if (nlist < 1) return fail("nlist must be >= 1");
+    ssmi_index* h = nullptr;
+    CHECK(ssmi_index_create_flat(d, storage_dtype, device, &h));
+    h->kind = SSMI_KIND_IVFFLAT;
+    DeviceGuard g(device);
+    if (ivf_create(h, nlist)) { ssmi_index_free(h); return 1; }
+    *out = h;
+    return 0;
+}
+
+int ssmi_index_set_centroids(ssmi_index* h, const float* centroids, int mem_kind) {
+    if (!h || !centroids) return fail("NULL argument");
+    if (h->kind != SSMI_KIND_IVFFLAT) return fail("set_centroids: not an IVF index");
+    if (h->ivf_ntotal != 0) return fail("set_centroids: index already holds vectors");
+    DeviceGuard g(h->device);
+    return install_centroids(h, centroids, mem_kind);
+}
+
+int ssmi_index_get_centroids(const ssmi_index* hc, float* out_host) {
+    ssmi_index* h = const_cast<ssmi_index*>(hc);
+    if (!h || !out_host) return fail("NULL argument");
+    if (h->kind != SSMI_KIND_IVFFLAT) return fail("get_centroids: not an IVF index");
+    if (!h->trained) return fail("get_centroids: index is not trained");
+    DeviceGuard g(h->device);
+    const RowStore& C = st(h)->cent32;
+    const long long seg_rows = 1ll << C.seg_shift;
+    for (long long r = 0; r < h->nlist;) {
+        const long long seg = r >> C.seg_shift, off = r & (seg_rows - 1);
+        const long long cnt = std::min<long long>(h->nlist - r, seg_rows - off);
+        HIPCHECK(hipMemcpy2D(out_host + (size_t)r * C.d, (size_t)C.d * 4, (const char*)C.segs[seg] + (size_t)off * C.row_bytes,
+                             C.row_bytes, (size_t)C.d * 4, (size_t)cnt, hipMemcpyDeviceToHost));
+        r += cnt;
+    }
+    return 0;
+}
+
+int ssmi_index_make_direct_map(ssmi_index* h) {
+    if (!h) return fail("NULL argument");
+    if (h->kind != SSMI_KIND_IVFFLAT) return 0;  // flat rows are their own direct map
+    DeviceGuard g(h->device);
+    IvfState* S = st(h);
+    std::vector<uint32_t> ids((size_t)h->ivf_slots_used);
+    if (!ids.empty())
+        HIPCHECK(hipMemcpy(ids.data(), S->d_slot_ids, ids.size() * 4, hipMemcpyDeviceToHost));
+    S->direct_map.assign((size_t)h->ivf_ntotal, -1);
+    for (int l = 0; l < h->nlist; ++l)
+        for (long long pos = 0; pos < S->size[l]; ++pos) {
+            const long long slot = (long long)S->pages[l][pos >> kPageShift] * kPageRows + (pos & (kPageRows - 1));
+            const uint32_t id = ids[(size_t)slot];
+            if (id >= (uint32_t)h->ivf_ntotal) return fail("internal: slot %lld holds id %u", slot, id);
+            S->direct_map[id] = slot;
+        }
+    S->has_direct_map = true;
+    return 0;
+}
+
+int ssmi_index_get_list_sizes(const ssmi_index* h, int64_t* out_host) {
+    if (!h || !out_host) return fail("NULL argument");
+    if (h->kind != SSMI_KIND_IVFFLAT) return fail("get_list_sizes: not an IVF index");
+    for (int l = 0; l < h->nlist; ++l) out_host[l] = st(h)->size[l];
+    return 0;
+}
+
+int ssmi_index_get_assignments(const ssmi_index* hc, int32_t* out_host) {
+    ssmi_index* h = const_cast<ssmi_index*>(hc);
+    if (!h || !out_host) return fail("NULL argument");
+    if (h->kind != SSMI_KIND_IVFFLAT) return fail("get_assignments: not an IVF index");
+    DeviceGuard g(h->device);
+    IvfState* S = st(h);
+    std::vector<uint32_t> ids((size_t)h->ivf_slots_used);
+    if (!ids.empty()) HIPCHECK(hipMemcpy(ids.data(), S->d_slot_ids, ids.size() * 4, hipMemcpyDeviceToHost));
+    for (int l = 0; l < h->nlist; ++l)
+        for (long long pos = 0; pos < S->size[l]; ++pos) {
+            const long long slot = (long long)S->pages[l][pos >> kPageShift] * kPageRows + (pos & (kPageRows - 1));
+            const uint32_t id = ids[(size_t)slot];
+            if (id >= (uint32_t)h->ivf_ntotal) return fail("internal: slot %lld holds id %u", slot, id);
+            out_host[id] = l;
+        }
+    return 0;
+}
+
+int ssmi_index_write(ssmi_index*, const char*) { return fail("persistence is not built yet"); }
+int ssmi_index_read(const char*, int, int, ssmi_index** out) { if (out) *out = nullptr; return fail("persistence is not built yet"); }
+
+}  // extern "C"

@@ -288,6 +288,13 @@ class IndexIVFFlat(_IndexBase):
         return out
 
 
+    def assignments(self) -> np.ndarray:
+        """List id of every stored vector, indexed by vector id (test introspection)."""
+        out = np.empty((self.ntotal,), dtype=np.int32)
+        _lib.check(self._lib.ssmi_index_get_assignments(self._handle(), out.ctypes.data))
+        return out
+
+
 def write_index(index: _IndexBase, path) -> None:
     """Stand-in for faiss.write_index (core/index_manager.py:241)."""
     _lib.check(index._lib.ssmi_index_write(index._handle(), os.fsencode(str(path))))

@@ -1,0 +1,140 @@
+"""GPU parity of the IVF-Flat path (coarse quantizer, list assignment, probe planning,
+bucketed list scan) against the oracle, through the C-ABI."""
+import numpy as np
+import pytest
+
+from conftest import unit_rows
+from oracle import flat_ip, ivf_flat
+
+pytestmark = pytest.mark.gpu
+
+
+def r16(a):
+    return a.astype(np.float16).astype(np.float32)
+
+
+def clustered_rows(n, d, ncl, seed):
+    """Unit rows with cluster structure so that IVF lists are meaningfully different."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    centers = rng.standard_normal((ncl, d), dtype=np.float32)
+    x = centers[rng.integers(0, ncl, n)] + 0.7 * rng.standard_normal((n, d), dtype=np.float32)
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+
+def make_ivf(ssa, d, nlist, storage="f32"):
+    return ssa.IndexIVFFlat(ssa.IndexFlatIP(d, storage=storage), d, nlist, ssa.METRIC_INNER_PRODUCT, storage=storage)
+
+
+@pytest.mark.parametrize("n,d,nlist,storage", [(6000, 256, 40, "f32"), (3000, 4096, 16, "f32"), (5000, 1024, 64, "f16"),
+                                                (2000, 100, 10, "f32")])
+def test_given_centroids_assignment_and_search_match_oracle(ssa, n, d, nlist, storage):
+    X = clustered_rows(n, d, nlist, 11)
+    C = clustered_rows(nlist, d, nlist, 12)
+    index = make_ivf(ssa, d, nlist, storage)
+    assert not index.is_trained and index.nlist == nlist and index.nprobe == 1
+    index.set_centroids(C)
+    assert index.is_trained
+    np.testing.assert_array_equal(index.get_centroids(), C)
+    index.add(X[: n // 2])
+    for s in range(n // 2, n, 16):  # the reference adds 16 vectors at a time (core/config.py:59)
+        index.add(X[s:s + 16])
+    assert index.ntotal == n
+    labels = index.assignments()
+    Cq = r16(C) if False else C
+    assert ivf_flat.assignment_is_valid(X, C, labels, rtol=2e-3 if n // 2 >= 9 else 1e-5), "vectors not in their best list"
+    np.testing.assert_array_equal(index.list_sizes(), np.bincount(labels, minlength=nlist))
+    Xs = r16(X) if storage == "f16" else X
+    Q = clustered_rows(5, d, nlist, 13)
+    for nprobe in (1, 3, nlist):
+        index.nprobe = nprobe
+        for k in (10, 100):
+            D, I = index.search(Q, k)
+            assert index.last_timing()["last_path"] == 2
+            Dr, Ir, _ = ivf_flat.search(Xs, C, labels, Q, k, nprobe)
+            ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xs, Q, rtol=1e-5, tie_rtol=1e-5)
+            assert ok, f"nprobe={nprobe} k={k}: {msg}"
+    # probing every list is exact search
+    index.nprobe = nlist
+    D, I = index.search(Q, 10)
+    Dr, Ir = flat_ip.search(Xs, Q, 10)
+    ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xs, Q, rtol=1e-5, tie_rtol=1e-5)
+    assert ok, msg
+    index.close()
+
+
+def test_large_query_batch_uses_mfma_coarse_quantizer(ssa):
+    n, d, nlist = 8000, 512, 32
+    X, C = clustered_rows(n, d, nlist, 21), clustered_rows(nlist, d, nlist, 22)
+    index = make_ivf(ssa, d, nlist)
+    index.set_centroids(C)
+    index.add(X)
+    labels = index.assignments()
+    Q = clustered_rows(64, d, nlist, 23)
+    index.nprobe = 4
+    D, I = index.search(Q, 10)
+    # coarse scores come from fp16-rounded centroids and queries on this path
+    Dr, Ir, _ = ivf_flat.search(X, C, labels, Q, 10, 4, C_coarse=r16(C), Q_coarse=r16(Q))
+    agree = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(I, Ir)])
+    assert agree > 0.97, agree
+    index.nprobe = nlist
+    D, I = index.search(Q, 10)
+    Dr, Ir = flat_ip.search(X, Q, 10)
+    ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, X, Q, rtol=1e-5, tie_rtol=1e-5)
+    assert ok, msg
+
+
+def test_train_kmeans_quality_and_recall(ssa):
+    n, d, nlist = 20000, 256, 50
+    X = clustered_rows(n, d, 50, 31)
+    index = make_ivf(ssa, d, nlist)
+    with pytest.raises(RuntimeError):
+        index.add(X[:10])           # untrained
+    with pytest.raises(RuntimeError):
+        index.search(X[:1], 5)
+    with pytest.raises(RuntimeError):
+        index.train(X[:10])         # fewer points than clusters
+    assert not index.is_trained
+    index.train(X)
+    assert index.is_trained
+    C = index.get_centroids()
+    _, obj_ref = ivf_flat.kmeans(X, nlist)
+    obj = ivf_flat.objective(X, C)
+    assert obj > 0.97 * obj_ref, (obj, obj_ref)
+    index.add(X)
+    assert int(index.list_sizes().sum()) == n
+    Q = clustered_rows(100, d, 50, 32)
+    index.nprobe = 10
+    D, I = index.search(Q, 10)
+    Dr, Ir = flat_ip.search(X, Q, 10)
+    recall = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(I, Ir)])
+    assert recall > 0.9, recall
+    assert (np.diff(D, axis=1) <= 0).all()
+
+
+def test_reconstruct_needs_direct_map(ssa):
+    n, d, nlist = 500, 64, 8
+    X, C = clustered_rows(n, d, nlist, 41), clustered_rows(nlist, d, nlist, 42)
+    index = make_ivf(ssa, d, nlist)
+    index.set_centroids(C)
+    index.add(X[:300])
+    with pytest.raises(RuntimeError):
+        index.reconstruct(0)        # like FAISS without a direct map (core/index_factory.py:275 catches it)
+    index.make_direct_map()
+    np.testing.assert_array_equal(index.reconstruct(17), X[17])
+    index.add(X[300:])              # the map is maintained by later adds
+    np.testing.assert_array_equal(index.reconstruct_batch([0, 299, 300, 499]), X[[0, 299, 300, 499]])
+    with pytest.raises(RuntimeError):
+        index.reconstruct(500)
+
+
+def test_empty_lists_and_short_results(ssa):
+    d, nlist = 64, 8
+    C = clustered_rows(nlist, d, nlist, 51)
+    index = make_ivf(ssa, d, nlist)
+    index.set_centroids(C)
+    D, I = index.search(C[:2], 5)
+    assert (I == -1).all()
+    index.add(C[:3] * 0.5)          # three vectors, three lists
+    index.nprobe = 2
+    D, I = index.search(C[0], 5)
+    assert I[0, 0] == 0 and (I[0, 2:] == -1).all() and (D[0, 2:] == flat_ip.NEG_MAX).all()
