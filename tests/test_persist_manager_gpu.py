@@ -1,0 +1,148 @@
+"""GPU tests: write_index/read_index (FAISS file layout) and the SemanticIndex surface."""
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import unit_rows
+from oracle import flat_ip
+
+pytestmark = pytest.mark.gpu
+
+
+def faiss_header(d, ntotal, trained=True):
+    return struct.pack("<iqqqBi", d, ntotal, 1 << 20, 1 << 20, 1 if trained else 0, 0)
+
+
+def test_flat_write_read_roundtrip_and_layout(ssa, tmp_path):
+    X = unit_rows(300, 72, 1)
+    index = ssa.IndexFlatIP(72)
+    index.add(X)
+    p = tmp_path / "vectors.faiss"
+    ssa.write_index(index, p)
+    raw = p.read_bytes()
+    # byte-for-byte the documented IndexFlatIP layout
+    assert raw == b"IxFI" + faiss_header(72, 300) + struct.pack("<Q", 300 * 72) + X.tobytes()
+    back = ssa.read_index(p)
+    assert type(back).__name__ == "IndexFlatIP" and back.ntotal == 300 and back.d == 72
+    np.testing.assert_array_equal(back.reconstruct_n(0, 300), X)
+    Q = unit_rows(3, 72, 2)
+    D0, I0 = index.search(Q, 10); D1, I1 = back.search(Q, 10)
+    np.testing.assert_array_equal(I0, I1); np.testing.assert_array_equal(D0, D1)
+    # an fp16-storage index round-trips exactly through the fp32 file
+    h = ssa.IndexFlatIP(72, storage="f16"); h.add(X)
+    ssa.write_index(h, tmp_path / "h.faiss")
+    hb = ssa.read_index(tmp_path / "h.faiss", storage="f16")
+    np.testing.assert_array_equal(hb.reconstruct_n(0, 300), X.astype(np.float16).astype(np.float32))
+
+
+def test_read_independently_written_ivf_file(ssa, tmp_path):
+    """A file assembled here with struct/numpy per the published FAISS layout (arbitrary ids, an
+    empty list, 'full' size table) must load and search like the oracle says."""
+    d, nlist, n = 64, 5, 200
+    X, C = unit_rows(n, d, 3), unit_rows(nlist, d, 4)
+    labels = np.argmax(X @ C.T, axis=1)
+    labels[labels == 2] = 3                       # list 2 stays empty
+    ids = np.arange(n, dtype=np.int64)
+    buf = b"IwFl" + faiss_header(d, n) + struct.pack("<QQ", nlist, 2)
+    buf += b"IxFI" + faiss_header(d, nlist) + struct.pack("<Q", nlist * d) + C.tobytes()
+    buf += struct.pack("<BQ", 0, 0)
+    buf += b"ilar" + struct.pack("<QQ", nlist, d * 4) + b"full" + struct.pack("<Q", nlist)
+    buf += b"".join(struct.pack("<Q", int((labels == l).sum())) for l in range(nlist))
+    for l in range(nlist):
+        m = np.nonzero(labels == l)[0]
+        if len(m):
+            buf += X[m].tobytes() + ids[m].tobytes()
+    p = tmp_path / "ivf.faiss"
+    p.write_bytes(buf)
+    index = ssa.read_index(p)
+    assert type(index).__name__ == "IndexIVFFlat" and index.ntotal == n and index.nlist == nlist and index.nprobe == 2
+    assert index.is_trained
+    np.testing.assert_array_equal(index.assignments(), labels)
+    np.testing.assert_array_equal(index.get_centroids(), C)
+    from oracle import ivf_flat
+    Q = unit_rows(4, d, 5)
+    D, I = index.search(Q, 10)
+    Dr, Ir, _ = ivf_flat.search(X, C, labels, Q, 10, 2)
+    ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, X, Q, 1e-5, 1e-5)
+    assert ok, msg
+    # and our writer reproduces a file that reads back identically
+    ssa.write_index(index, tmp_path / "again.faiss")
+    again = ssa.read_index(tmp_path / "again.faiss")
+    np.testing.assert_array_equal(again.assignments(), labels)
+    D2, I2 = again.search(Q, 10)
+    np.testing.assert_array_equal(I, I2)
+    with pytest.raises(RuntimeError):
+        ssa.read_index(tmp_path / "missing.faiss")
+    (tmp_path / "bad.faiss").write_bytes(b"IHNf" + b"\0" * 64)
+    with pytest.raises(RuntimeError, match="unsupported index type"):
+        ssa.read_index(tmp_path / "bad.faiss")
+
+
+def test_factory_rebuild_and_compact_on_device(ssa):
+    F, C, T = ssa.IndexFactory, ssa.IndexConfig, ssa.IndexType
+    X = unit_rows(1500, 128, 7)
+    flat = F.create_index(C(T.FLAT, 128))
+    flat.add(X)
+    calls = []
+    ivf, ok = F.rebuild_index(flat, C(T.IVF_FLAT, 128, nlist=12, nprobe=12), lambda c, t, s: calls.append((c, t)))
+    assert ok and F.detect_index_type(ivf) is T.IVF_FLAT and ivf.ntotal == 1500 and ivf.nprobe == 12
+    assert calls[0] == (0, 1500) and calls[-1] == (1500, 1500)
+    Q = unit_rows(3, 128, 8)
+    D, I = ivf.search(Q, 5); Dr, Ir = flat.search(Q, 5)
+    np.testing.assert_array_equal(I, Ir)          # nprobe == nlist is exact
+    same, ok = F.rebuild_index(ivf, C(T.FLAT, 128))
+    assert not ok and same is ivf                 # IVF without a direct map cannot be reconstructed (as with FAISS)
+    keep = [5, 3, 1499, 700]
+    small, mapping, ok = F.compact_index(flat, keep)
+    assert ok and mapping == {3: 0, 5: 1, 700: 2, 1499: 3} and small.ntotal == 4
+    np.testing.assert_array_equal(small.reconstruct_n(0, 4), X[[3, 5, 700, 1499]])
+    empty, mapping, ok = F.compact_index(flat, [])
+    assert ok and mapping == {} and empty.ntotal == 0
+    fresh, ok = F.rebuild_index(F.create_index(C(T.FLAT, 128)), C(T.IVF_FLAT, 128))
+    assert ok and fresh.ntotal == 0 and not fresh.is_trained
+
+
+def test_semantic_index_lifecycle(ssa, tmp_path):
+    from semantic_search_amd.index_manager import SemanticIndex
+    d = 96
+    X = unit_rows(1200, d, 9)
+    si = SemanticIndex("photos", embedding_dim=d, index_type="ivf-flat", base_path=tmp_path)
+    assert si.get_index_type() == "ivf_flat"
+    ids = []
+    for s in range(0, 1200, 16):                  # reference batches: 16 images (core/config.py:59)
+        b = X[s:s + 16]
+        ids += si.add_vectors(b, [f"/img/{s + i}.jpg" for i in range(len(b))], [f"/th/{s + i}.jpg" for i in range(len(b))],
+                              [(1.0, 10)] * len(b))
+    assert ids == list(range(1200))               # ids continue through the training buffer phase
+    assert si._faiss_index.is_trained and si._faiss_index.ntotal == 1200   # trained at >= max(10*nlist, 1000)
+    si._faiss_index.nprobe = 100
+    res = si.search(X[17], top_k=5)
+    assert res[0].vector_id == 17 and res[0].file_path == "/img/17.jpg" and abs(res[0].score - 1.0) < 1e-5
+    batch = si.search_batch(X[[3, 900]], top_k=3)
+    assert [r[0].vector_id for r in batch] == [3, 900]
+    stats = si.get_stats()
+    assert stats["vector_count"] == 1200 and stats["index_type"] == "ivf_flat" and stats["index_params"]["nlist"] == 100
+    si.save()
+    assert si.faiss_path.exists() and si.config_path.exists()
+    # reload from disk
+    si2 = SemanticIndex("photos", embedding_dim=4096, base_path=tmp_path)
+    assert si2.embedding_dim == d and si2.get_index_type() == "ivf_flat" and si2._faiss_index.ntotal == 1200
+    # rebuild to flat fails without a direct map (reference behaviour), works after make_direct_map
+    assert si2.rebuild("flat")["success"] is False
+    si2._faiss_index.make_direct_map()
+    out = si2.rebuild("flat")
+    assert out == {"success": True, "old_type": "ivf_flat", "new_type": "flat", "old_count": 1200, "new_count": 1200}
+    # delete two files, compact, ids are renumbered
+    assert si2.db.remove_image("/img/0.jpg") and si2.db.remove_image("/img/5.jpg")
+    assert si2.needs_compaction() == (False, 2, pytest.approx(2 / 1200 * 100))
+    out = si2.compact()
+    assert out["success"] and out["compacted"] and out["new_count"] == 1198 and out["removed_count"] == 2
+    res = si2.search(X[17], top_k=1)
+    assert res[0].file_path == "/img/17.jpg" and res[0].vector_id == 15
+    # exclusion search drops candidates close to a negative vector
+    res = si2.search_with_exclusion(X[17], [X[17]], top_k=5, exclusion_threshold=0.9)
+    assert all(r.file_path != "/img/17.jpg" for r in res)
+    vid = si2.add_document_vector(X[0], "/doc/a.pdf#1", "/th/a.jpg")
+    assert vid == 1198
+    si2.close(); si.db.close()
