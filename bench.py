@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--storage", default="f32", choices=["f32", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the batch-1024/4096 MFMA side measurements")
     ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
     return ap.parse_args()
 
@@ -130,11 +131,54 @@ def main():
                 "unit": "GB/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
     roof["traffic"] = None
+    try:  # HBM bytes per launch from the committed rocprofv3 PMC pass of this exact workload
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_flat_f32_1M_b1_pmc.json")))
+        if (args.n, args.d, args.batch, args.storage, world) == (1_000_000, 4096, 1, "f32", 1):
+            for name, v in prof["kernels"].items():
+                if "flat_scan_topk_kernel" in name:
+                    roof["traffic"] = v["hbm_bytes_per_launch_corrected"]
+                    roof["traffic_source"] = "profiles/r01_flat_f32_1M_b1_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)"
+    except Exception:
+        pass
+    roof["algorithmic_bytes_per_launch"] = algo_bytes
     roof["kernel"] = {0: "flat_scan_topk_kernel", 1: "flat_mfma_topk_kernel", 2: "ivf_scan_topk_kernel"}[timing["last_path"]]
     roof["kernel_avg_ms"] = scan_avg_ms
     roof["launches_timed"] = int(len(scan_ms))
     roof["db_passes_per_launch"] = int(passes)
     roof["flop_per_byte"] = intensity
+
+    # side measurements (not `value`): large query batches over the same sharded database run the
+    # MFMA contraction (on the fp16 shadow copy when storage is f32); few steps, same timing rules
+    extra = {}
+    if not args.no_extra:
+        for B, steps in ((1024, 5), (4096, 3)):
+            Qb = torch.randn((2, B, args.d), generator=g, dtype=torch.float32)
+            Qb = (Qb / Qb.norm(dim=-1, keepdim=True)).to(dev)
+            index.search(Qb[0], args.k)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                index.search(Qb[i % 2], args.k)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            el = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            kms = float(np.mean(index.local.scan_times_ms(steps)))
+            tl = index.local.last_timing()
+            flops = 2.0 * B * n_local * args.d
+            extra["batch_%d" % B] = {
+                "qps": B * steps / el, "ms_per_step": el / steps * 1e3, "kernel_avg_ms": kms,
+                "kernel": "flat_mfma_pp_kernel" if tl["last_path"] == 1 else "flat_scan_topk_kernel",
+                "achieved_tflops_per_gpu": flops / (kms * 1e-3) / 1e12,
+                "mfma_frac_of_2.5PF": flops / (kms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                "operand_dtype": "f16 (shadow copy of the f32 rows), f32 accumulate" if args.storage == "f32" else "f16, f32 accumulate",
+            }
 
     if rank == 0:
         qps = args.batch * args.steps / elapsed
@@ -158,6 +202,7 @@ def main():
                 "storage": args.storage, "parallelism": "rowshard%d" % world,
             },
             "roofline": roof,
+            "extra": extra,
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(index.local, args.d, args.k, args.cpu_sample_rows, Q[0].expand(4, -1) if args.batch == 1 else Q[0])

@@ -202,6 +202,7 @@ int ssmi_index_free(ssmi_index* h) {
     (void)hipStreamSynchronize(h->stream);
     ivf_destroy(h);
     h->rows.destroy();
+    if (h->has_shadow) h->shadow16.destroy();
     for (int i = 0; i < kWsSlots; ++i) if (h->ws[i]) (void)hipFree(h->ws[i]);
     for (int i = 0; i < ssmi_index::kEvRing; ++i)
         for (int j = 0; j < 3; ++j) if (h->ev[i][j]) (void)hipEventDestroy(h->ev[i][j]);
@@ -369,6 +370,18 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
                  int64_t* Idev, int64_t id_offset, hipStream_t s, bool record) {
     if (R.dtype == SSMI_F16 && (R.ld % 64) == 0 && nq >= mfma_min_batch())
         return store_search_mfma(h, R, nq, qdev, k, Ddev, Idev, id_offset, s, record);
+    if (&R == &h->rows && h->kind == SSMI_KIND_FLAT && R.dtype == SSMI_F32 && (R.ld % 64) == 0 &&
+        nq >= mfma_min_batch() && !getenv("SSMI_NO_SHADOW")) {
+        // bring the fp16 shadow up to date, then run the MFMA contraction on it
+        if (!h->has_shadow) { CHECK(h->shadow16.init(R.d, SSMI_F16)); h->has_shadow = true; }
+        RowStore& S = h->shadow16;
+        if (S.nrows < R.nrows) {
+            CHECK(S.reserve(R.nrows, s));
+            HIPCHECK(launch_shadow_rows(R.view(), (void* const*)S.d_segs, S.seg_shift, S.nrows, R.nrows - S.nrows, s));
+            S.nrows = R.nrows;
+        }
+        return store_search_mfma(h, S, nq, qdev, k, Ddev, Idev, id_offset, s, record);
+    }
     ScanPlan p;
     std::string err;
     // bound the partial-list buffer: process queries in batches

@@ -36,6 +36,10 @@ struct ssmi_index {
     int device = 0;
     int num_cu = 256;
     ssmi::RowStore rows;  // Flat: the database.  IVF: the slot store (pages of list members)
+    // fp16 copy of an fp32 Flat database, built lazily by the first large-batch search so that
+    // it can run on the MFMA kernel (costs +50 % HBM; batch-1..8 searches keep using the fp32 rows)
+    ssmi::RowStore shadow16;
+    bool has_shadow = false;
     hipStream_t stream = nullptr;
     // ring of (scan start, scan stop, merge stop) event triples, one per search call
     static const int kEvRing = 256;

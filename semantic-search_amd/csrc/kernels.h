@@ -48,6 +48,8 @@ hipError_t launch_gather_rows(const RowView& X, int dtype, const int64_t* ids, l
 // K10: append unit-norm gaussian rows [row0,row0+n)
 hipError_t launch_fill_random_unit(const RowView& X, int dtype, void* const* segs_rw, long long row0, long long n,
                                    int d, uint64_t seed, hipStream_t s);
+// fp32 store rows -> fp16 shadow store rows
+hipError_t launch_shadow_rows(const RowView& src, void* const* dsegs, int dshift, long long row0, long long n, hipStream_t s);
 // fill (nq,k) outputs with the "no result" padding
 hipError_t launch_fill_empty(float* D, int64_t* I, long long n, hipStream_t s);
 // pad queries (nq,d) -> (nq,ld) fp32 (zero tail)

@@ -23,61 +23,9 @@
 // TRIG entries a wave folds it into the query's sorted k-list (topk.h) and
 // raises the threshold.  At the end of the slice the k-list IS the per-slice
 // partial result that K3 (merge.hip) merges across slices.
-#include "kernels.h"
-#include "topk.h"
+#include "mfma_common.h"
 
 namespace ssmi {
-
-typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-
-static constexpr int TM = 256, TN = 256, BK = 64;
-static constexpr int TILE_BYTES = TM * BK * 2;  // one operand tile: 32 KiB
-static constexpr int CAND_CAP = 512, CAND_TRIG = 256;
-
-struct MfmaParams {
-    RowView X;                 // fp16 rows, ld % 64 == 0
-    const _Float16* Qh;        // [nqt*256][ld] fp16, zero rows beyond nq
-    int nq, k, nqt, nslices;
-    long long rows_per_slice;  // multiple of 256
-    skey_t* partial;           // [nq][nslices][k]
-    skey_t* cand;              // [gridDim.x][256][CAND_CAP]
-};
-
-#define GLDS16(gptr, ldsptr)                                                                      \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),      \
-                                     (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
-
-template <int R>
-__device__ __forceinline__ void compact_query(int ql, int q, const MfmaParams& P, int slice, skey_t* cand_q,
-                                              float* thr_l, unsigned* cnt_l, unsigned* kept_l) {
-    const int lane = lane_id();
-    skey_t* kept = P.partial + ((size_t)q * P.nslices + slice) * P.k;
-    WaveTopK<R> t;
-    t.init();
-    if (kept_l[ql]) t.merge_from(kept, P.k);
-    skey_t thrk = t.kth(P.k);
-    const int n = (int)min(cnt_l[ql], (unsigned)CAND_CAP);
-    for (int base = 0; base < n; base += 64) {
-        const skey_t c = (base + lane < n) ? cand_q[base + lane] : 0;
-        unsigned long long mask = __ballot(c > thrk);
-        while (mask) {
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const skey_t key = readlane64(c, j);
-            if (key > thrk) {
-                t.insert(key);
-                thrk = t.kth(P.k);
-            }
-        }
-    }
-    t.store(kept, P.k);
-    if (lane == 0) {
-        kept_l[ql] = 1;
-        cnt_l[ql] = 0;
-        thr_l[ql] = (thrk == 0) ? SSMI_NEG_MAX : key_score(thrk);
-    }
-}
 
 template <int R>
 __global__ void __launch_bounds__(512) flat_mfma_topk_kernel(MfmaParams P) {
@@ -267,6 +215,8 @@ hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, con
     P.rows_per_slice = p.rows_per_slice; P.partial = partial; P.cand = (skey_t*)cand;
     int r = 1;
     while (64 * r < k) r <<= 1;
+    const char* env = getenv("SSMI_MFMA_VARIANT");
+    if (!(env && env[0] == '1')) return launch_flat_mfma_pp(P, r, p.grid, p.lds, s);
 #define LAUNCH_R(RR)                                                                                              \
     case RR: {                                                                                                    \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(flat_mfma_topk_kernel<RR>),                        \

@@ -139,6 +139,30 @@ hipError_t launch_fill_random_unit(const RowView& X, int dtype, void* const* seg
     return hipGetLastError();
 }
 
+// fp32 store rows [row0,row0+n) -> fp16 store rows (same row numbers): the fp16 shadow that lets
+// large query batches over an fp32 index run on the MFMA kernel
+__global__ void shadow_rows_kernel(RowView src, void* const* dsegs, int dshift, long long row0, long long n) {
+    const long long i = blockIdx.x;
+    if (i >= n) return;
+    const long long r = row0 + i;
+    const float* s = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(src.segs[r >> src.seg_shift]) +
+                                                    (size_t)(r & ((1ll << src.seg_shift) - 1)) * (size_t)src.ld * 4);
+    __half* d = reinterpret_cast<__half*>(row_ptr_rw(dsegs, dshift, r, (size_t)src.ld * 2));
+    for (int e = threadIdx.x * 4; e < src.ld; e += blockDim.x * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(s + e);
+        __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+        uint2 o;
+        o.x = *reinterpret_cast<unsigned*>(&a);
+        o.y = *reinterpret_cast<unsigned*>(&b);
+        *reinterpret_cast<uint2*>(d + e) = o;
+    }
+}
+hipError_t launch_shadow_rows(const RowView& src, void* const* dsegs, int dshift, long long row0, long long n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(shadow_rows_kernel, dim3((unsigned)n), dim3(256), 0, s, src, dsegs, dshift, row0, n);
+    return hipGetLastError();
+}
+
 __global__ void fill_empty_kernel(float* D, int64_t* I, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { D[i] = SSMI_NEG_MAX; I[i] = -1; }

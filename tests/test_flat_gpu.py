@@ -45,8 +45,29 @@ def test_flat_f32_matches_oracle(ssa, n, d, nq, k):
     index = ssa.IndexFlatIP(d)
     index.add(X)
     assert index.ntotal == n and index.d == d and index.is_trained
-    _check(index, X, Q, k)
+    if nq >= 9 and d % 64 == 0:
+        # large batches over fp32 rows run the MFMA contraction on an fp16 shadow copy:
+        # north-star tolerance (scores 1e-3 relative, ids equal except at 1e-3-relative ties)
+        D, I = index.search(Q, k)
+        assert index.last_timing()["last_path"] == 1
+        Dr, Ir = flat_ip.search(X, Q, k)
+        ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, X, Q, rtol=1e-3, tie_rtol=1e-3, atol=2e-5)
+        assert ok, msg
+        recall = np.mean([len(set(a) & set(b)) / k for a, b in zip(I, Ir)])
+        assert recall > 0.99
+    else:
+        _check(index, X, Q, k)
     index.close()
+
+
+def test_flat_f32_large_batch_exact_path_without_shadow(ssa, monkeypatch):
+    """SSMI_NO_SHADOW keeps large batches on the exact fp32 streaming scan (8 queries per pass)."""
+    monkeypatch.setenv("SSMI_NO_SHADOW", "1")
+    X, Q = unit_rows(10000, 4096, 1234), unit_rows(100, 4096, 4321)
+    index = ssa.IndexFlatIP(4096)
+    index.add(X)
+    _check(index, X, Q, 10)
+    assert index.last_timing()["last_path"] == 0
 
 
 @pytest.mark.parametrize("n,d,nq,k", [(10000, 4096, 1, 10), (10000, 4096, 8, 10), (3000, 4096, 2, 100),
