@@ -33,21 +33,20 @@ __device__ __forceinline__ void compact_query(int ql, int q, const MfmaParams& P
     WaveTopK<R> t;
     t.init();
     if (kept_l[ql]) t.merge_from(kept, P.k);
-    skey_t thrk = t.kth(P.k);
     const int n = (int)min(cnt_l[ql], (unsigned)CAND_CAP);
-    for (int base = 0; base < n; base += 64) {
-        const skey_t c = (base + lane < n) ? cand_q[base + lane] : 0;
-        unsigned long long mask = __ballot(c > thrk);
-        while (mask) {
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const skey_t key = readlane64(c, j);
-            if (key > thrk) {
-                t.insert(key);
-                thrk = t.kth(P.k);
-            }
+    // candidates arrive unsorted: sort them 256 at a time in registers (bitonic network), then one
+    // bitonic merge with the kept list - far cheaper than one sorted insertion per candidate
+    for (int base = 0; base < n; base += 256) {
+        WaveTopK<4> c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = base + r * 64 + lane;
+            c.v[r] = (e < n) ? cand_q[e] : 0;
         }
+        c.sort_desc();
+        t.merge_regs(c);
     }
+    const skey_t thrk = t.kth(P.k);
     t.store(kept, P.k);
     if (lane == 0) {
         kept_l[ql] = 1;

@@ -138,13 +138,24 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
             __builtin_amdgcn_s_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            if (p + 3 < np) issue(p + 3);
+            // the four DMA instructions of slab p+3 are spread between the MFMAs so that their
+            // issue cost hides under matrix-pipe time
+            const bool pre = (p + 3 < np);
+            unsigned char* dst = smem + ((p + 3) & (RING - 1)) * PHASE_LDS + (wave * 2) * 1024;
+            const size_t koff = (size_t)(p + 3) * 64;
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int m = 0; m < 8; ++m)
+            for (int m = 0; m < 8; ++m) {
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], b[n], acc[m][n], 0, 0, 0);
+                if (pre) {
+                    if (m == 0) GLDS16(asrc[0] + koff, dst);
+                    if (m == 2) GLDS16(asrc[1] + koff, dst + 1024);
+                    if (m == 4) GLDS16(qsrc[0] + koff, dst + SLAB);
+                    if (m == 6) GLDS16(qsrc[1] + koff, dst + SLAB + 1024);
+                }
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();

@@ -88,6 +88,63 @@ struct WaveTopK {
             const skey_t b = (j < len) ? src[j] : 0;
             v[r] = kmax(v[r], b);
         }
+        bitonic_merge();
+    }
+
+    // Merge another register-resident sorted list (any length) into this one.
+    template <int RC>
+    __device__ __forceinline__ void merge_regs(const WaveTopK<RC>& c) {
+        const int lane = lane_id();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            // reversed element KP-1-(r*64+lane) of c = register R-1-r, lane 63-lane
+            skey_t b = 0;
+            if (R - 1 - r < RC) {
+                const skey_t src = c.v[(R - 1 - r) < RC ? (R - 1 - r) : 0];
+                int lo = (int)(unsigned)(src & 0xFFFFFFFFull), hi = (int)(unsigned)(src >> 32);
+                lo = __shfl(lo, 63 - lane); hi = __shfl(hi, 63 - lane);
+                b = ((skey_t)(unsigned)hi << 32) | (skey_t)(unsigned)lo;
+            }
+            v[r] = kmax(v[r], b);
+        }
+        bitonic_merge();
+    }
+
+    // Full bitonic sort of arbitrary contents, best first.
+    __device__ __forceinline__ void sort_desc() {
+        const int lane = lane_id();
+#pragma unroll
+        for (int size = 2; size <= KP; size <<= 1) {
+#pragma unroll
+            for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+                if (stride >= 64) {
+                    const int rs = stride >> 6;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if ((r & rs) == 0) {
+                            const bool desc = ((r * 64) & size) == 0;  // size >= 128: the bit lives in r
+                            const skey_t a = v[r], b = v[r + rs];
+                            const skey_t hi = kmax(a, b), lo = kmin(a, b);
+                            v[r] = desc ? hi : lo;
+                            v[r + rs] = desc ? lo : hi;
+                        }
+                    }
+                } else {
+                    const bool lower = (lane & stride) == 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const bool desc = (((r * 64 + lane) & size) == 0);
+                        const skey_t p = shfl_xor64(v[r], stride);
+                        v[r] = (desc == lower) ? kmax(v[r], p) : kmin(v[r], p);
+                    }
+                }
+            }
+        }
+    }
+
+    // re-sort a bitonic sequence, best first
+    __device__ __forceinline__ void bitonic_merge() {
+        const int lane = lane_id();
 #pragma unroll
         for (int s = R / 2; s >= 1; s >>= 1) {
 #pragma unroll
