@@ -109,10 +109,13 @@ int ssmi_index_search(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind,
 
 /* merge step of a sharded search (the RCCL all-gather's consumer; no reference
  * counterpart - the reference is single-index).  Inputs are `nlists` result
- * sets laid out [nlists][nq][k] on the device (what all_gather produces);
+ * sets on the device, each (nq,k) row-major; set l starts at D_lists +
+ * l*d_list_stride and I_lists + l*i_list_stride (strides in elements, so one
+ * all-gathered buffer holding both scores and ids can be merged in place);
  * output is the (nq,k) top-k of their union, same ordering rules. */
 int ssmi_topk_merge(int device, int nlists, int64_t nq, int k,
-                    const float* D_lists, const int64_t* I_lists,
+                    const float* D_lists, int64_t d_list_stride,
+                    const int64_t* I_lists, int64_t i_list_stride,
                     float* D_out, int64_t* I_out, void* stream);
 
 /* ---- read back ---------------------------------------------------------- */

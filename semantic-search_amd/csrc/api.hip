@@ -464,15 +464,17 @@ int ssmi_index_search(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind,
     return 0;
 }
 
-int ssmi_topk_merge(int device, int nlists, int64_t nq, int k, const float* D_lists, const int64_t* I_lists,
-                    float* D_out, int64_t* I_out, void* stream) {
+int ssmi_topk_merge(int device, int nlists, int64_t nq, int k, const float* D_lists, int64_t d_list_stride,
+                    const int64_t* I_lists, int64_t i_list_stride, float* D_out, int64_t* I_out, void* stream) {
     if (nlists < 1 || nq < 0 || k < 1) return fail("bad merge shape");
     if (k > kMaxK) return fail("k=%d exceeds the supported maximum %d", k, kMaxK);
     if (nq == 0) return 0;
     if (!D_lists || !I_lists || !D_out || !I_out) return fail("NULL buffer");
     DeviceGuard g(device);
     if (!g.ok) return fail("hipSetDevice(%d) failed", device);
-    HIPCHECK(launch_merge_lists(D_lists, I_lists, nlists, (int)nq, k, D_out, I_out, (hipStream_t)stream));
+    if (d_list_stride < nq * k || i_list_stride < nq * k) return fail("list stride smaller than nq*k");
+    HIPCHECK(launch_merge_lists(D_lists, d_list_stride, I_lists, i_list_stride, nlists, (int)nq, k, D_out, I_out,
+                                (hipStream_t)stream));
     return 0;
 }
 

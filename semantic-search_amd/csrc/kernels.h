@@ -35,9 +35,9 @@ hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, con
 // K3: merge P sorted k-lists of keys per query -> (D, I)
 hipError_t launch_merge_keys(const skey_t* partial, int nq, int P, int k, float* D, int64_t* I,
                              int64_t id_offset, hipStream_t s);
-// K3': merge `nlists` (D,I) result sets [nlists][nq][k] -> (D, I)
-hipError_t launch_merge_lists(const float* Dl, const int64_t* Il, int nlists, int nq, int k, float* D,
-                              int64_t* I, hipStream_t s);
+// K3': merge `nlists` (D,I) result sets, each (nq,k) row-major, list l at Dl + l*d_stride / Il + l*i_stride
+hipError_t launch_merge_lists(const float* Dl, long long d_stride, const int64_t* Il, long long i_stride, int nlists,
+                              int nq, int k, float* D, int64_t* I, hipStream_t s);
 
 // K4: rows (n,d) of src dtype -> storage rows [row0, row0+n) with zero padding to ld
 hipError_t launch_cvt_store(const void* src, int src_dtype, long long n, int d, const RowView& X, int dst_dtype,

@@ -36,15 +36,34 @@ __global__ void merge_keys_kernel(const skey_t* __restrict__ partial, int P, int
     const int nwaves = (int)(blockDim.x >> 6);
     WaveTopK<R> t;
     t.init();
-    for (int p = wave; p < P; p += nwaves) t.merge_from(partial + ((size_t)q * P + p) * k, k);
+    if (R == 1) {
+        // short lists: treat the P*k keys as one unsorted pool, 256 per wave-step, all loads of a
+        // step in flight together (a chain of P dependent little merges is latency-bound)
+        const skey_t* pool = partial + (size_t)q * P * k;
+        const int total = P * k;
+        const int lane = lane_id();
+        for (int base = wave * 256; base < total; base += nwaves * 256) {
+            WaveTopK<4> c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = base + r * 64 + lane;
+                c.v[r] = (e < total) ? pool[e] : 0;
+            }
+            c.sort_desc();
+            t.merge_regs(c);
+        }
+    } else {
+        for (int p = wave; p < P; p += nwaves) t.merge_from(partial + ((size_t)q * P + p) * k, k);
+    }
     block_merge<R>(t, lds, wave, nwaves);
     if (wave == 0) write_result<R>(t, k, D + (size_t)q * k, I + (size_t)q * k, id_offset);
 }
 
 // lists given as (D, I) pairs laid out [nlists][nq][k]
 template <int R>
-__global__ void merge_lists_kernel(const float* __restrict__ Dl, const int64_t* __restrict__ Il, int nlists, int nq,
-                                   int k, float* __restrict__ D, int64_t* __restrict__ I) {
+__global__ void merge_lists_kernel(const float* __restrict__ Dl, long long d_stride, const int64_t* __restrict__ Il,
+                                   long long i_stride, int nlists, int nq, int k, float* __restrict__ D,
+                                   int64_t* __restrict__ I) {
     extern __shared__ __align__(16) unsigned char smem[];
     skey_t* lds = reinterpret_cast<skey_t*>(smem);
     const int KP = WaveTopK<R>::KP;
@@ -57,10 +76,10 @@ __global__ void merge_lists_kernel(const float* __restrict__ Dl, const int64_t* 
     WaveTopK<R> t;
     t.init();
     for (int p = wave; p < nlists; p += nwaves) {
-        const size_t base = ((size_t)p * nq + q) * k;
+        const size_t dbase = (size_t)p * d_stride + (size_t)q * k, ibase = (size_t)p * i_stride + (size_t)q * k;
         for (int e = lane; e < k; e += 64) {
-            const int64_t id = Il[base + e];
-            slot[e] = (id < 0) ? 0 : make_key(Dl[base + e], (uint32_t)id);
+            const int64_t id = Il[ibase + e];
+            slot[e] = (id < 0) ? 0 : make_key(Dl[dbase + e], (uint32_t)id);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave visible to itself
         __builtin_amdgcn_wave_barrier();
@@ -88,6 +107,7 @@ static hipError_t dispatch_r(int r, F f) {
 
 static int merge_waves(int P, int kp) {
     int w = P < 16 ? (P < 1 ? 1 : P) : 16;
+    if (kp == 64 && P > 4) w = (P * 64 / 256 + 1) < 16 ? (P * 64 / 256 + 1) : 16;
     while (w > 1 && (size_t)w * kp * sizeof(skey_t) > 64 * 1024) --w;
     return w;
 }
@@ -105,15 +125,15 @@ hipError_t launch_merge_keys(const skey_t* partial, int nq, int P, int k, float*
     });
 }
 
-hipError_t launch_merge_lists(const float* Dl, const int64_t* Il, int nlists, int nq, int k, float* D, int64_t* I,
-                              hipStream_t s) {
+hipError_t launch_merge_lists(const float* Dl, long long d_stride, const int64_t* Il, long long i_stride, int nlists,
+                              int nq, int k, float* D, int64_t* I, hipStream_t s) {
     if (nq <= 0) return hipSuccess;
     const int r = pow2_ceil((k + 63) / 64);
     const int w = merge_waves(nlists, 64 * r);
     const size_t lds = (size_t)w * 64 * r * sizeof(skey_t);
     return dispatch_r(r, [&](auto rc) {
         constexpr int R = decltype(rc)::value;
-        hipLaunchKernelGGL((merge_lists_kernel<R>), dim3(nq), dim3(64 * w), lds, s, Dl, Il, nlists, nq, k, D, I);
+        hipLaunchKernelGGL((merge_lists_kernel<R>), dim3(nq), dim3(64 * w), lds, s, Dl, d_stride, Il, i_stride, nlists, nq, k, D, I);
         return hipGetLastError();
     });
 }

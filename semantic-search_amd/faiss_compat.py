@@ -155,7 +155,7 @@ class _IndexBase:
         _lib.check(self._lib.ssmi_index_add_random_unit(self._handle(), int(n), int(seed)))
 
     # -- search -----------------------------------------------------------
-    def search(self, x, k: int, id_offset: int = 0):
+    def search(self, x, k: int, id_offset: int = 0, out=None):
         """(D, I) = top-k inner products of each query row.
 
         numpy in -> numpy out (D float32 (n,k) sorted descending, I int64, -1 padded).
@@ -171,8 +171,14 @@ class _IndexBase:
             self._check_tensor(x, "search")
             x = x.contiguous().float()
             nq = x.shape[0]
-            D = torch.empty((nq, k), dtype=torch.float32, device=x.device)
-            I = torch.empty((nq, k), dtype=torch.int64, device=x.device)
+            if out is not None:  # caller-provided contiguous (nq,k) device tensors (e.g. views of one gather buffer)
+                D, I = out
+                if (tuple(D.shape) != (nq, k) or tuple(I.shape) != (nq, k) or D.dtype != torch.float32 or
+                        I.dtype != torch.int64 or not D.is_contiguous() or not I.is_contiguous() or D.device != x.device):
+                    raise ValueError("search: out must be contiguous (nq,k) float32 / int64 tensors on the index's device")
+            else:
+                D = torch.empty((nq, k), dtype=torch.float32, device=x.device)
+                I = torch.empty((nq, k), dtype=torch.int64, device=x.device)
             stream = torch.cuda.current_stream(x.device).cuda_stream
             _lib.check(self._lib.ssmi_index_search(self._handle(), nq, x.data_ptr(), _lib.DEVICE, k, D.data_ptr(),
                                                    I.data_ptr(), _lib.DEVICE, int(id_offset), stream))
@@ -315,18 +321,27 @@ def read_index(path, storage: Optional[str] = None, device: Optional[int] = None
 
 
 def topk_merge(D_lists: torch.Tensor, I_lists: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Merge `nlists` result sets laid out (nlists, nq, k) on a ROCm device into the
-    (nq, k) top-k of their union (the consumer of the RCCL all-gather)."""
+    """Merge `nlists` result sets (nlists, nq, k) on a ROCm device into the (nq, k) top-k of
+    their union (the consumer of the RCCL all-gather).  The list dimension may be strided
+    (views into one gathered buffer); the inner (nq, k) block must be contiguous."""
     if D_lists.dim() != 3 or D_lists.shape != I_lists.shape:
         raise ValueError("topk_merge: expected (nlists, nq, k) tensors of equal shape")
     if not D_lists.is_cuda or D_lists.device != I_lists.device:
         raise RuntimeError("topk_merge: tensors must live on the same ROCm device")
-    D_lists = D_lists.contiguous().float()
-    I_lists = I_lists.contiguous().long()
+    if D_lists.dtype != torch.float32 or I_lists.dtype != torch.int64:
+        D_lists, I_lists = D_lists.float(), I_lists.long()
     nl, nq, k = D_lists.shape
+
+    def inner_ok(t):
+        return t.stride(2) == 1 and t.stride(1) == k and (nl == 1 or t.stride(0) >= nq * k)
+    if not inner_ok(D_lists):
+        D_lists = D_lists.contiguous()
+    if not inner_ok(I_lists):
+        I_lists = I_lists.contiguous()
     D = torch.empty((nq, k), dtype=torch.float32, device=D_lists.device)
     I = torch.empty((nq, k), dtype=torch.int64, device=D_lists.device)
     stream = torch.cuda.current_stream(D_lists.device).cuda_stream
-    _lib.check(_lib.load().ssmi_topk_merge(D_lists.device.index, nl, nq, k, D_lists.data_ptr(), I_lists.data_ptr(),
-                                           D.data_ptr(), I.data_ptr(), stream))
+    _lib.check(_lib.load().ssmi_topk_merge(D_lists.device.index, nl, nq, k, D_lists.data_ptr(),
+                                           D_lists.stride(0) if nl > 1 else nq * k, I_lists.data_ptr(),
+                                           I_lists.stride(0) if nl > 1 else nq * k, D.data_ptr(), I.data_ptr(), stream))
     return D, I

@@ -36,16 +36,28 @@ def exchange_offsets(n_local: int, group=None, device="cpu") -> Tuple[int, int]:
     return sum(counts[:rank]), sum(counts)
 
 
-def gather_topk(D: torch.Tensor, I: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """all_gather per-rank (B,k) results into (world, B, k) tensors (one collective each)."""
+def packed_result_buffers(B: int, k: int, device) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """One int64 buffer holding a rank's (B,k) int64 ids followed by its (B,k) fp32 scores, so that a
+    sharded search needs ONE all-gather (the collective is latency-bound: 12*B*k bytes per rank)."""
+    n = B * k
+    words = n + (n + 1) // 2
+    buf = torch.empty((words,), dtype=torch.int64, device=device)
+    I = buf[:n].view(B, k)
+    D = buf[n:].view(torch.float32)[:n].view(B, k)
+    return buf, D, I
+
+
+def gather_packed(buf: torch.Tensor, B: int, k: int, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """all_gather the packed per-rank buffers; returns strided (world, B, k) views of scores and ids."""
     world = dist.get_world_size(group)
-    B, k = D.shape
-    # concatenation layout (world*B, k): accepted by both the RCCL and the gloo backend
-    Dg = torch.empty((world * B, k), dtype=D.dtype, device=D.device)
-    Ig = torch.empty((world * B, k), dtype=I.dtype, device=I.device)
-    dist.all_gather_into_tensor(Dg, D.contiguous(), group=group)
-    dist.all_gather_into_tensor(Ig, I.contiguous(), group=group)
-    return Dg.view(world, B, k), Ig.view(world, B, k)
+    words = buf.numel()
+    g = torch.empty((world * words,), dtype=torch.int64, device=buf.device)
+    dist.all_gather_into_tensor(g, buf, group=group)
+    g = g.view(world, words)
+    n = B * k
+    Ig = g[:, :n].unflatten(1, (B, k))
+    Dg = g[:, n:].view(torch.float32)[:, :n].unflatten(1, (B, k))
+    return Dg, Ig
 
 
 class ShardedFlatIP:
@@ -81,8 +93,10 @@ class ShardedFlatIP:
 
     def search(self, q, k: int):
         """q: (B,d) tensor, identical on every rank.  Returns the global (D, I) on every rank."""
-        D, I = self.local.search(q, k, id_offset=self.row_offset)
         if self.world == 1:
-            return D, I
-        Dg, Ig = gather_topk(D, I, self.group)
+            return self.local.search(q, k, id_offset=self.row_offset)
+        B = q.shape[0] if q.dim() == 2 else 1
+        buf, D, I = packed_result_buffers(B, k, q.device)
+        self.local.search(q, k, id_offset=self.row_offset, out=(D, I))
+        Dg, Ig = gather_packed(buf, B, k, self.group)
         return self._merge(Dg, Ig)

@@ -168,6 +168,34 @@ def test_topk_merge_of_shards_equals_unsharded(ssa):
     assert ok, msg
 
 
+def test_packed_gather_layout_merges_in_place(ssa):
+    """The sharded path's single-collective layout: per-shard [ids | scores] buffers stacked as an
+    all-gather would, merged through strided views (no repacking)."""
+    import torch
+    from semantic_search_amd.faiss_compat import topk_merge
+    from semantic_search_amd.sharded import packed_result_buffers
+    d, k, B = 256, 7, 5          # odd B*k: the fp32 half starts on an 8-byte boundary anyway
+    X, Q = unit_rows(2000, d, 31), unit_rows(B, d, 32)
+    Qd = torch.from_numpy(Q).cuda()
+    bounds = [0, 700, 1300, 2000]
+    bufs = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        shard = ssa.IndexFlatIP(d)
+        shard.add(X[a:b])
+        buf, D, I = packed_result_buffers(B, k, Qd.device)
+        shard.search(Qd, k, id_offset=a, out=(D, I))
+        bufs.append(buf)
+    g = torch.stack(bufs)                                   # (world, words): what all_gather_into_tensor yields
+    n = B * k
+    Ig = g[:, :n].unflatten(1, (B, k))
+    Dg = g[:, n:].view(torch.float32)[:, :n].unflatten(1, (B, k))
+    assert not Dg.is_contiguous()
+    D, I = topk_merge(Dg, Ig)
+    Dr, Ir = flat_ip.search(X, Q, k)
+    ok, msg, _ = flat_ip.check_against(D.cpu().numpy(), I.cpu().numpy(), Dr, Ir, X, Q, RTOL, RTOL)
+    assert ok, msg
+
+
 def test_errors_are_runtime_errors(ssa):
     index = ssa.IndexFlatIP(64)
     index.add(unit_rows(10, 64, 1))

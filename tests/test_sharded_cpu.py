@@ -30,16 +30,20 @@ class OracleLocalIndex:
     def add(self, x):
         self.X = np.concatenate([self.X, np.asarray(x, np.float32)])
 
-    def search(self, q, k, id_offset=0):
+    def search(self, q, k, id_offset=0, out=None):
         from oracle import flat_ip
         D, I = flat_ip.search(self.X, q.numpy(), k)
         I = np.where(I >= 0, I + id_offset, -1)
+        if out is not None:
+            out[0].copy_(torch.from_numpy(D)); out[1].copy_(torch.from_numpy(I))
+            return out
         return torch.from_numpy(D), torch.from_numpy(I)
 
 
 def oracle_merge(Dg, Ig):
     from oracle import flat_ip
     w, nq, k = Dg.shape
+    assert Dg.dtype == torch.float32 and Ig.dtype == torch.int64
     D = Dg.permute(1, 0, 2).reshape(nq, w * k).numpy()
     I = Ig.permute(1, 0, 2).reshape(nq, w * k).numpy()
     outD = np.full((nq, k), flat_ip.NEG_MAX, np.float32); outI = np.full((nq, k), -1, np.int64)
