@@ -89,6 +89,11 @@ int ssmi_index_get_centroids(const ssmi_index* h, float* out_host);
  *                           core/index_factory.py:307,411
  * x: (n,d) row-major of src_dtype, host or device. */
 int ssmi_index_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind);
+/* list-sharded IVF (no reference counterpart; north-star: "IVF lists by list across
+ * the GPUs"): every rank passes the same vectors; this handle keeps the ones whose
+ * list l has l % nshards == shard, stored under the global ids id0 + i. */
+int ssmi_index_add_ivf_shard(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind,
+                             int64_t id0, int shard, int nshards);
 /* bench/test helper (no reference counterpart): append n rows of i.i.d.
  * N(0,1) components, L2-normalised per row, generated on the device. */
 int ssmi_index_add_random_unit(ssmi_index* h, int64_t n, uint64_t seed);

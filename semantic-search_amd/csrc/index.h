@@ -98,6 +98,7 @@ int ivf_create(ssmi_index* h, int nlist);
 void ivf_destroy(ssmi_index* h);
 int ivf_train(ssmi_index* h, int64_t n, const float* x, int mem_kind);
 int ivf_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind);
+int ivf_add_shard(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind, int64_t id0, int shard, int nshards);
 int ivf_add_random_unit(ssmi_index* h, int64_t n, uint64_t seed);
 int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev, int64_t* Idev, int64_t id_offset,
                hipStream_t s);

@@ -77,13 +77,14 @@ __global__ void rows_to_f32_kernel(const S* __restrict__ src, int d, int ld, flo
 template <typename T>
 __global__ void scatter_rows_kernel(const float* __restrict__ src, int ld, const int* __restrict__ dst_slot,
                                     void* const* segs, int seg_shift, uint32_t* __restrict__ slot_ids, uint32_t id0,
-                                    const uint32_t* __restrict__ ids) {
+                                    const uint32_t* __restrict__ ids, const int* __restrict__ src_idx) {
     const size_t i = blockIdx.x;
+    const size_t si = src_idx ? (size_t)src_idx[i] : i;
     const long long slot = dst_slot[i];
     const long long mask = (1ll << seg_shift) - 1;
     T* dst = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(segs[slot >> seg_shift]) +
                                   (size_t)(slot & mask) * (size_t)ld * sizeof(T));
-    for (int e = threadIdx.x; e < ld; e += blockDim.x) dst[e] = (T)src[i * ld + e];
+    for (int e = threadIdx.x; e < ld; e += blockDim.x) dst[e] = (T)src[si * ld + e];
     if (threadIdx.x == 0) slot_ids[slot] = ids ? ids[i] : id0 + (uint32_t)i;
 }
 
@@ -511,7 +512,9 @@ static int ensure_slots(ssmi_index* h, long long npages) {
 }
 
 // append vectors (on the device as (n, ld) fp32) to given lists; ids == nullptr: sequential ids from ntotal
-static int ivf_append_preassigned(ssmi_index* h, int64_t n, const float* xdev, const int* labels, const uint32_t* ids_host) {
+static int ivf_append_preassigned(ssmi_index* h, int64_t n, const float* xdev, const int* labels, const uint32_t* ids_host,
+                                  const int* src_idx_host = nullptr) {
+    if (n == 0) return 0;
     IvfState* S = st(h);
     std::vector<int> dst((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
@@ -525,20 +528,25 @@ static int ivf_append_preassigned(ssmi_index* h, int64_t n, const float* xdev, c
     }
     if (S->npages * kPageRows >= (1ll << 31)) return fail("IVF slot store would exceed 2^31 slots");
     CHECK(ensure_slots(h, S->npages));
-    CHECK(ensure_ws(h, 9, (size_t)n * 8));
+    CHECK(ensure_ws(h, 9, (size_t)n * 12));
     HIPCHECK(hipMemcpyAsync(h->ws[9], dst.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     const uint32_t* ids_dev = nullptr;
+    const int* src_idx_dev = nullptr;
     if (ids_host) {
         ids_dev = (const uint32_t*)((char*)h->ws[9] + (size_t)n * 4);
         HIPCHECK(hipMemcpyAsync((void*)ids_dev, ids_host, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     }
+    if (src_idx_host) {
+        src_idx_dev = (const int*)((char*)h->ws[9] + (size_t)n * 8);
+        HIPCHECK(hipMemcpyAsync((void*)src_idx_dev, src_idx_host, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    }
     const RowStore& R = h->rows;
     if (R.dtype == SSMI_F32)
         hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)h->ws[9],
-                           (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, (uint32_t)h->ivf_ntotal, ids_dev);
+                           (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, (uint32_t)h->ivf_ntotal, ids_dev, src_idx_dev);
     else
         hipLaunchKernelGGL((scatter_rows_kernel<__half>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)h->ws[9],
-                           (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, (uint32_t)h->ivf_ntotal, ids_dev);
+                           (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, (uint32_t)h->ivf_ntotal, ids_dev, src_idx_dev);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(h->stream));
     h->ivf_ntotal += n;
@@ -551,6 +559,35 @@ static int ivf_add_device_f32(ssmi_index* h, int64_t n, const float* xdev) {
     std::vector<int> labels;
     CHECK(assign_to_centroids(h, n, xdev, &labels));
     return ivf_append_preassigned(h, n, xdev, labels.data(), nullptr);
+}
+
+// list-sharded add: every rank sees the same vectors, assigns them all, and keeps those whose list l
+// satisfies l % nshards == shard, under their GLOBAL ids id0 + i
+int ivf_add_shard(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind, int64_t id0, int shard, int nshards) {
+    if (!h->trained) return fail("add on an untrained IVF index (call train first)");
+    if (nshards < 1 || shard < 0 || shard >= nshards) return fail("bad shard %d of %d", shard, nshards);
+    if (id0 < 0 || (unsigned long long)(id0 + n) >= 0xFFFFFFFFull) return fail("ids would exceed 2^32-2");
+    if (st(h)->has_direct_map) return fail("a list-sharded index cannot maintain a direct map");
+    const RowStore& R = h->rows;
+    const size_t el = src_dtype == SSMI_F32 ? 4 : 2;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(1 << 16, ((size_t)1 << 30) / ((size_t)R.ld * 4)));
+    std::vector<int> labels, sel_labels, sel_src;
+    std::vector<uint32_t> sel_ids;
+    for (int64_t done = 0; done < n; done += chunk) {
+        const int64_t cnt = std::min(chunk, n - done);
+        const float* xdev = nullptr;
+        CHECK(rows_to_device_f32(h, cnt, (const char*)x + (size_t)done * R.d * el, src_dtype, mem_kind, &xdev));
+        CHECK(assign_to_centroids(h, cnt, xdev, &labels));
+        sel_labels.clear(); sel_src.clear(); sel_ids.clear();
+        for (int64_t i = 0; i < cnt; ++i)
+            if (labels[i] % nshards == shard) {
+                sel_labels.push_back(labels[i]);
+                sel_src.push_back((int)i);
+                sel_ids.push_back((uint32_t)(id0 + done + i));
+            }
+        CHECK(ivf_append_preassigned(h, (int64_t)sel_labels.size(), xdev, sel_labels.data(), sel_ids.data(), sel_src.data()));
+    }
+    return 0;
 }
 
 int ivf_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind) {
@@ -723,6 +760,19 @@ int ssmi_index_make_direct_map(ssmi_index* h) {
         }
     S->has_direct_map = true;
     return 0;
+}
+
+int ssmi_index_add_ivf_shard(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind, int64_t id0,
+                             int shard, int nshards) {
+    if (!h) return fail("NULL index");
+    if (h->kind != SSMI_KIND_IVFFLAT) return fail("add_ivf_shard: not an IVF index");
+    if (n < 0) return fail("negative n");
+    if (n == 0) return 0;
+    if (!x) return fail("NULL vectors");
+    if (src_dtype != SSMI_F32 && src_dtype != SSMI_F16) return fail("unknown source dtype %d", src_dtype);
+    if (mem_kind != SSMI_HOST && mem_kind != SSMI_DEVICE) return fail("unknown mem_kind %d", mem_kind);
+    DeviceGuard g(h->device);
+    return ivf_add_shard(h, n, x, src_dtype, mem_kind, id0, shard, nshards);
 }
 
 int ssmi_index_get_list_sizes(const ssmi_index* h, int64_t* out_host) {

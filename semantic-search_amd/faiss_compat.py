@@ -273,6 +273,25 @@ class IndexIVFFlat(_IndexBase):
     def nprobe(self, v: int) -> None:
         _lib.check(self._lib.ssmi_index_set_nprobe(self._handle(), int(v)))
 
+    def add_shard(self, x, id0: int, shard: int, nshards: int) -> None:
+        """List-sharded add: keep the vectors of x whose list l has l % nshards == shard, with global
+        ids id0 + i (every rank of a sharded index passes the same x)."""
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            self._check_tensor(x, "add_shard")
+            if x.dtype not in (torch.float32, torch.float16):
+                x = x.float()
+            x = x.contiguous()
+            torch.cuda.current_stream(x.device).synchronize()
+            dt = _lib.F32 if x.dtype == torch.float32 else _lib.F16
+            _lib.check(self._lib.ssmi_index_add_ivf_shard(self._handle(), x.shape[0], x.data_ptr(), dt, _lib.DEVICE,
+                                                          int(id0), int(shard), int(nshards)))
+            return
+        if isinstance(x, torch.Tensor):
+            x = x.numpy()
+        x = _as_f32_matrix(x, self.d, "add_shard")
+        _lib.check(self._lib.ssmi_index_add_ivf_shard(self._handle(), x.shape[0], x.ctypes.data, _lib.F32, _lib.HOST,
+                                                      int(id0), int(shard), int(nshards)))
+
     def make_direct_map(self, _enable: bool = True) -> None:
         """Like faiss: without a direct map reconstruct() raises RuntimeError."""
         _lib.check(self._lib.ssmi_index_make_direct_map(self._handle()))

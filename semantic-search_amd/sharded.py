@@ -100,3 +100,62 @@ class ShardedFlatIP:
         self.local.search(q, k, id_offset=self.row_offset, out=(D, I))
         Dg, Ig = gather_packed(buf, B, k, self.group)
         return self._merge(Dg, Ig)
+
+
+class ShardedIVFFlat:
+    """IVF-Flat sharded BY LIST across ranks: every rank holds the same centroids, list l lives
+    wholly on rank l % world.  Every rank passes the same vectors to add() (as the reference's
+    single add stream would) and keeps its own lists' members under global ids; a search probes
+    the same nprobe lists everywhere, each rank scans the probed lists it owns (the others are
+    empty locally), and the per-rank top-k are all-gathered and merged like the Flat case."""
+
+    def __init__(self, d: int, nlist: int, storage: str = "f32", group=None, device: Optional[int] = None,
+                 rank: Optional[int] = None, world: Optional[int] = None):
+        from .faiss_compat import IndexFlatIP, IndexIVFFlat, METRIC_INNER_PRODUCT, topk_merge
+        self.d, self.nlist, self.group = d, nlist, group
+        self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.rank = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
+        self.local = IndexIVFFlat(IndexFlatIP(d, storage=storage, device=device), d, nlist, METRIC_INNER_PRODUCT,
+                                  storage=storage, device=device)
+        self._merge = topk_merge
+        self.ntotal = 0
+
+    @property
+    def nprobe(self) -> int:
+        return self.local.nprobe
+
+    @nprobe.setter
+    def nprobe(self, v: int) -> None:
+        self.local.nprobe = v
+
+    @property
+    def is_trained(self) -> bool:
+        return self.local.is_trained
+
+    def train(self, x) -> None:
+        """Rank 0 runs k-means; the centroids are broadcast so that every rank quantizes identically."""
+        if self.world == 1 or not dist.is_initialized():
+            self.local.train(x)
+            return
+        dev = torch.device("cuda", self.local.device)
+        c = torch.empty((self.nlist, self.d), dtype=torch.float32, device=dev)
+        if self.rank == 0:
+            self.local.train(x)
+            c.copy_(torch.from_numpy(self.local.get_centroids()))
+        dist.broadcast(c, src=0, group=self.group)
+        if self.rank != 0:
+            self.local.set_centroids(c.cpu().numpy())
+
+    def add(self, x) -> None:
+        n = int(x.shape[0])
+        self.local.add_shard(x, self.ntotal, self.rank, self.world)
+        self.ntotal += n
+
+    def search(self, q, k: int):
+        if self.world == 1 or not dist.is_initialized():
+            return self.local.search(q, k)
+        B = q.shape[0] if q.dim() == 2 else 1
+        buf, D, I = packed_result_buffers(B, k, q.device)
+        self.local.search(q, k, out=(D, I))
+        Dg, Ig = gather_packed(buf, B, k, self.group)
+        return self._merge(Dg, Ig)

@@ -138,3 +138,36 @@ def test_empty_lists_and_short_results(ssa):
     index.nprobe = 2
     D, I = index.search(C[0], 5)
     assert I[0, 0] == 0 and (I[0, 2:] == -1).all() and (D[0, 2:] == flat_ip.NEG_MAX).all()
+
+
+def test_list_sharded_ivf_equals_unsharded(ssa):
+    """Logical 3-way sharding by list on one GPU: same centroids everywhere, list l on shard l % 3,
+    global ids; merging the shards' results must reproduce the single-index search."""
+    import torch
+    from semantic_search_amd.faiss_compat import topk_merge
+    from semantic_search_amd.sharded import ShardedIVFFlat
+    n, d, nlist, world = 4000, 128, 24, 3
+    X, C = clustered_rows(n, d, nlist, 61), clustered_rows(nlist, d, nlist, 62)
+    whole = make_ivf(ssa, d, nlist)
+    whole.set_centroids(C)
+    whole.add(X)
+    shards = [ShardedIVFFlat(d, nlist, rank=r, world=world) for r in range(world)]
+    for sh in shards:
+        sh.local.set_centroids(C)
+        for s in range(0, n, 1000):
+            sh.add(X[s:s + 1000])
+        assert sh.ntotal == n
+    sizes = np.stack([sh.local.list_sizes() for sh in shards])
+    np.testing.assert_array_equal(sizes.sum(axis=0), whole.list_sizes())
+    for l in range(nlist):
+        assert (sizes[:, l] > 0).sum() <= 1 and (sizes[l % world, l] == whole.list_sizes()[l])
+    Q = torch.from_numpy(clustered_rows(6, d, nlist, 63)).cuda()
+    for nprobe in (1, 5, nlist):
+        whole.nprobe = nprobe
+        Dw, Iw = whole.search(Q, 10)
+        parts = []
+        for sh in shards:
+            sh.nprobe = nprobe
+            parts.append(sh.local.search(Q, 10))
+        D, I = topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+        assert torch.equal(I, Iw) and torch.equal(D, Dw), nprobe
