@@ -19,32 +19,53 @@ struct MfmaParams {
     long long rows_per_slice;  // multiple of 256
     skey_t* partial;           // [nq][nslices][k]
     skey_t* cand;              // [gridDim.x][256][CAND_CAP]
+#ifdef SSMI_STAMP
+    unsigned long long* dbg;   // diagnostic build only: per-wave cycle sums
+#endif
 };
 
+// same with a compile-time byte offset on the global address.  The instruction adds its immediate
+// field to BOTH the global address and the LDS address (M0 + imm), so the LDS base is pre-biased.
+#define GLDS16O(gptr, ldsptr, imm)                                                                \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),      \
+                                     (__attribute__((address_space(3))) void*)((ldsptr) - (imm)), 16, imm, 0)
 #define GLDS16(gptr, ldsptr)                                                                      \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),      \
                                      (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
 
+// LDS words behind the four operand slabs: thr[256] (float), cnt[256], kept[256], flag
+static constexpr int EPI_LDS_BYTES = 3 * 256 * 4 + 16;
+
+// Fold the candidate buffer of one query into its sorted k-list and raise its threshold.
+// One wave per query.  Candidates arrive unsorted: they are sorted in registers (bitonic
+// network, 64 or 256 at a time) and merged with the kept list by one bitonic merge - far cheaper
+// than one sorted insertion per candidate.
 template <int R>
 __device__ __forceinline__ void compact_query(int ql, int q, const MfmaParams& P, int slice, skey_t* cand_q,
                                               float* thr_l, unsigned* cnt_l, unsigned* kept_l) {
     const int lane = lane_id();
+    const int n = (int)min(cnt_l[ql], (unsigned)CAND_CAP);
+    if (n == 0 && kept_l[ql]) return;  // nothing new: list and threshold stand
     skey_t* kept = P.partial + ((size_t)q * P.nslices + slice) * P.k;
     WaveTopK<R> t;
     t.init();
     if (kept_l[ql]) t.merge_from(kept, P.k);
-    const int n = (int)min(cnt_l[ql], (unsigned)CAND_CAP);
-    // candidates arrive unsorted: sort them 256 at a time in registers (bitonic network), then one
-    // bitonic merge with the kept list - far cheaper than one sorted insertion per candidate
-    for (int base = 0; base < n; base += 256) {
-        WaveTopK<4> c;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int e = base + r * 64 + lane;
-            c.v[r] = (e < n) ? cand_q[e] : 0;
-        }
+    if (n <= 64) {
+        WaveTopK<1> c;
+        c.v[0] = (lane < n) ? cand_q[lane] : 0;
         c.sort_desc();
         t.merge_regs(c);
+    } else {
+        for (int base = 0; base < n; base += 256) {
+            WaveTopK<4> c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = base + r * 64 + lane;
+                c.v[r] = (e < n) ? cand_q[e] : 0;
+            }
+            c.sort_desc();
+            t.merge_regs(c);
+        }
     }
     const skey_t thrk = t.kth(P.k);
     t.store(kept, P.k);
@@ -52,6 +73,89 @@ __device__ __forceinline__ void compact_query(int ql, int q, const MfmaParams& P
         kept_l[ql] = 1;
         cnt_l[ql] = 0;
         thr_l[ql] = (thrk == 0) ? SSMI_NEG_MAX : key_score(thrk);
+    }
+}
+
+// LDS atomic add / store issued as opaque instructions: after an LDS-DMA (global_load_lds) the
+// compiler's wait-count pass puts `s_waitcnt vmcnt(0)` in front of every LDS atomic or store it
+// can see, because it cannot tell that they do not touch the DMA's destination slabs; in the
+// epilogue that would stall on the next tile's pipeline fill (an HBM round trip per row tile).
+__device__ __forceinline__ unsigned lds_add_rtn(unsigned* p, unsigned v) {
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned*)p;
+    unsigned old;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(addr), "v"(v) : "memory");
+    return old;
+}
+__device__ __forceinline__ void lds_store(unsigned* p, unsigned v) {
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned*)p;
+    asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(addr), "v"(v) : "memory");
+}
+
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// Threshold filter over one wave's 128 x 64 accumulator tile (acc[m][n]: rows m*16 + fq*4 + i of
+// the wave's row half, query n*16 + frow of its query quarter).  Per query column the 32 values
+// of a lane are first reduced to per-accumulator maxima and one column maximum: in steady state
+// almost no column holds a survivor and the whole column costs 20 VALU instructions and one
+// wave-uniform branch; a column that does is searched accumulator by accumulator.
+// FULL = false adds the row-range test for the last, partial row tile of a slice (its padding
+// rows repeat the last valid row).
+template <bool FULL>
+__device__ __forceinline__ void filter_tile(const f32x4_t (&acc)[8][4], int wm, int wn, int frow, int fq, long long row0,
+                                            int rows_valid, skey_t* cand, const float* thr_l, unsigned* cnt_l,
+                                            unsigned* flag_l) {
+    // keep the per-column LDS/global addresses out of the main loop's register budget: they are
+    // recomputed here per row tile instead of being hoisted (and spilled) by the compiler
+    asm volatile("" : "+v"(frow));
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int ql = wn * 64 + n * 16 + frow;
+        const float thr = thr_l[ql];
+        float mm[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) mm[m] = vmax2(vmax3(acc[m][n][0], acc[m][n][1], acc[m][n][2]), acc[m][n][3]);
+        const float mx = vmax3(vmax3(mm[0], mm[1], mm[2]), vmax3(mm[3], mm[4], mm[5]), vmax2(mm[6], mm[7]));
+        if (__builtin_amdgcn_ballot_w64(mx >= thr) == 0) continue;
+        // survivors in this column: count them per lane, reserve their slots with ONE LDS atomic per
+        // lane, then store them (accumulators without a survivor in any lane are skipped wave-wide)
+        unsigned long long hot[8];
+        unsigned c = 0;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            hot[m] = __builtin_amdgcn_ballot_w64(mm[m] >= thr);
+            if (hot[m] == 0) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                c += (acc[m][n][i] >= thr && (FULL || wm * 128 + m * 16 + fq * 4 + i < rows_valid)) ? 1u : 0u;
+        }
+        unsigned pos = 0;
+        if (c) {
+            pos = lds_add_rtn(&cnt_l[ql], c);
+            if (pos + c >= (unsigned)CAND_TRIG) lds_store(flag_l, 1u);
+        }
+        skey_t* cq = cand + (size_t)ql * CAND_CAP;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            if (hot[m] == 0) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float s = acc[m][n][i];
+                const int rr = wm * 128 + m * 16 + fq * 4 + i;
+                if (s >= thr && (FULL || rr < rows_valid)) {
+                    if (pos < (unsigned)CAND_CAP) cq[pos] = make_key(s, (uint32_t)(row0 + rr));
+                    ++pos;
+                }
+            }
+        }
     }
 }
 

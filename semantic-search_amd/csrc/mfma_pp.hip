@@ -24,6 +24,10 @@
 // c ^ ((-(r >> 2)) & 3) (applied to the DMA SOURCE address and to the reads),
 // which makes every ds_read_b128 fragment read bank-conflict free.
 #include "mfma_common.h"
+#ifdef SSMI_STAMP
+#include <cstdio>
+#include <vector>
+#endif
 
 namespace ssmi {
 
@@ -37,6 +41,7 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
     float* thr_l = reinterpret_cast<float*>(smem + RING * PHASE_LDS);
     unsigned* cnt_l = reinterpret_cast<unsigned*>(thr_l + 256);
     unsigned* kept_l = cnt_l + 256;
+    unsigned* flag_l = kept_l + 256;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -57,6 +62,7 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
         cnt_l[tid] = 0;
         kept_l[tid] = 0;
     }
+    if (tid == 0) *flag_l = 0;
     __syncthreads();
 
     const int ld = P.X.ld;
@@ -94,23 +100,33 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
                       (size_t)(r & seg_mask) * (size_t)ld * 2 + slot_coff[j];
         }
     };
-    auto issue = [&](int p) {  // DMA of phase p's slabs into ring slot p & 3
-        unsigned char* dst = smem + (p & (RING - 1)) * PHASE_LDS + (wave * 2) * 1024;
-        const size_t koff = (size_t)p * 64;
-        GLDS16(asrc[0] + koff, dst);
-        GLDS16(asrc[1] + koff, dst + 1024);
-        GLDS16(qsrc[0] + koff, dst + SLAB);
-        GLDS16(qsrc[1] + koff, dst + SLAB + 1024);
-    };
+    // DMA of phase PH's slabs (PH = 0, 1, 2: the pipeline fill of a row tile) into ring slot PH; the K
+    // offset rides in the instruction's immediate field, so the fill needs no extra address registers
+#define ISSUE_FILL(PH)                                                                       \
+    {                                                                                        \
+        unsigned char* dst_ = smem + (PH) * PHASE_LDS + (wave * 2) * 1024;                   \
+        GLDS16O(asrc[0], dst_, (PH) * 64);                                                   \
+        GLDS16O(asrc[1], dst_ + 1024, (PH) * 64);                                            \
+        GLDS16O(qsrc[0], dst_ + SLAB, (PH) * 64);                                            \
+        GLDS16O(qsrc[1], dst_ + SLAB + 1024, (PH) * 64);                                     \
+    }
 
     if (r_begin < r_end) {
         set_rows(r_begin);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        issue(0);
-        if (1 < np) issue(1);
-        if (2 < np) issue(2);
+        ISSUE_FILL(0)
+        if (1 < np) ISSUE_FILL(1)
+        if (2 < np) ISSUE_FILL(2)
     }
 
+#ifdef SSMI_STAMP
+    unsigned long long stv[6] = {0, 0, 0, 0, 0, 0};
+#define STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stv[i] += now_ - stl_; stl_ = now_; }
+    unsigned long long stl_ = __builtin_amdgcn_s_memtime();
+#else
+#define STAMP(i)
+#endif
+    unsigned tiles_done = 0;
     for (long long row0 = r_begin; row0 < r_end; row0 += TM) {
         f32x4_t acc[8][4];
 #pragma unroll
@@ -124,90 +140,95 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier event behind
+        STAMP(0)
 
         for (int p = 0; p < np; ++p) {
             const unsigned char* slab = smem + (p & (RING - 1)) * PHASE_LDS;
+            // ---- LOAD segment (the partner group owns the matrix pipe meanwhile) ----
+            // DMA of slab p+3 into the ring slot of slab p-1: every ds_read of slab p-1 was retired by
+            // an lgkmcnt(0) that its wave executed BEFORE a barrier event this wave has already passed.
+            if (p + 3 < np) {
+                unsigned char* dst = smem + ((p + 3) & (RING - 1)) * PHASE_LDS + (wave * 2) * 1024;
+                const size_t koff = (size_t)(p + 3) * 64;
+                GLDS16(asrc[0] + koff, dst);
+                GLDS16(asrc[1] + koff, dst + 1024);
+                GLDS16(qsrc[0] + koff, dst + SLAB);
+                GLDS16(qsrc[1] + koff, dst + SLAB + 1024);
+            }
             half8_t a[8], b[4];
 #pragma unroll
             for (int m = 0; m < 8; ++m) a[m] = *reinterpret_cast<const half8_t*>(slab + a_off + m * 16 * 64);
 #pragma unroll
             for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const half8_t*>(slab + b_off + n * 16 * 64);
-            // own DMA of slab p+1 must have landed before this phase's first barrier
-            if (p + 2 < np) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            // own DMA of slab p+1 must have landed before this phase's first barrier; the four
+            // instructions just issued (slab p+3) and the four of slab p+2 may stay in flight
+            if (p + 3 < np) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (p + 2 < np) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers: slab p may be recycled
             __builtin_amdgcn_sched_barrier(0);
-            // the four DMA instructions of slab p+3 are spread between the MFMAs so that their
-            // issue cost hides under matrix-pipe time
-            const bool pre = (p + 3 < np);
-            unsigned char* dst = smem + ((p + 3) & (RING - 1)) * PHASE_LDS + (wave * 2) * 1024;
-            const size_t koff = (size_t)(p + 3) * 64;
+            __builtin_amdgcn_s_barrier();
+            // ---- MFMA segment ----
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
+            for (int m = 0; m < 8; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], b[n], acc[m][n], 0, 0, 0);
-                if (pre) {
-                    if (m == 0) GLDS16(asrc[0] + koff, dst);
-                    if (m == 2) GLDS16(asrc[1] + koff, dst + 1024);
-                    if (m == 4) GLDS16(qsrc[0] + koff, dst + SLAB);
-                    if (m == 6) GLDS16(qsrc[1] + koff, dst + SLAB + 1024);
-                }
-            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
         }
         if (wm == 0) __builtin_amdgcn_s_barrier();  // realign the two groups
+        STAMP(1)
 
         // start the next row tile's pipeline before the epilogue: every ring slot is free now
         const long long next0 = row0 + TM;
         if (next0 < r_end) {
             set_rows(next0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            issue(0);
-            if (1 < np) issue(1);
-            if (2 < np) issue(2);
+            ISSUE_FILL(0)
+            if (1 < np) ISSUE_FILL(1)
+            if (2 < np) ISSUE_FILL(2)
         }
 
+        STAMP(2)
         // ---- epilogue: threshold filter, survivors -> candidate buffers ----
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int ql = wn * 64 + n * 16 + frow;
-            const float thr = thr_l[ql];
-            skey_t* cq = cand + (size_t)ql * CAND_CAP;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float s = acc[m][n][i];
-                    const long long r = row0 + wm * 128 + m * 16 + fq * 4 + i;
-                    if (s >= thr && r < r_end) {
-                        const unsigned pos = atomicAdd(&cnt_l[ql], 1u);
-                        if (pos < (unsigned)CAND_CAP) cq[pos] = make_key(s, (uint32_t)r);
-                    }
-                }
-            }
-        }
+        const long long left = r_end - row0;
+        if (left >= TM) filter_tile<true>(acc, wm, wn, frow, fq, row0, TM, cand, thr_l, cnt_l, flag_l);
+        else filter_tile<false>(acc, wm, wn, frow, fq, row0, (int)left, cand, thr_l, cnt_l, flag_l);
+        STAMP(3)
         __syncthreads();
-        const int need = (tid < 256) ? (cnt_l[tid] >= (unsigned)CAND_TRIG) : 0;
-        if (__syncthreads_or(need)) {
+        STAMP(4)
+        // fold the buffers after row tiles 1, 4, 16, 64, ... of the slice and whenever one is half full
+        ++tiles_done;
+        if (((tiles_done & (tiles_done - 1)) == 0 && (tiles_done & 0x55555555u)) || *flag_l) {
             for (int ql = wave; ql < 256; ql += 8)
-                if (cnt_l[ql] >= (unsigned)CAND_TRIG && q0 + ql < P.nq)
-                    compact_query<R>(ql, q0 + ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
+                if (q0 + ql < P.nq) compact_query<R>(ql, q0 + ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
             __syncthreads();
+            if (tid == 0) *flag_l = 0;
         }
+        STAMP(5)
     }
+#ifdef SSMI_STAMP
+    if (lane == 0 && P.dbg)
+        for (int i = 0; i < 6; ++i) P.dbg[((size_t)blockIdx.x * 8 + wave) * 6 + i] = stv[i];
+#endif
 
+    // ---- end of slice: fold what is left; the k-list is the partial result ----
     __syncthreads();
     for (int ql = wave; ql < 256; ql += 8)
         if (q0 + ql < P.nq) compact_query<R>(ql, q0 + ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
 }
 
-hipError_t launch_flat_mfma_pp(const MfmaParams& P, int r, int grid, size_t lds, hipStream_t s) {
+hipError_t launch_flat_mfma_pp(const MfmaParams& P_in, int r, int grid, size_t lds, hipStream_t s) {
     hipError_t e;
+    MfmaParams P = P_in;
+#ifdef SSMI_STAMP
+    static unsigned long long* dbg = nullptr;
+    if (!dbg) (void)hipMalloc((void**)&dbg, 4096 * 8 * 6 * 8);
+    P.dbg = dbg;
+#endif
 #define LAUNCH_R(RR)                                                                                    \
     case RR: {                                                                                          \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(flat_mfma_pp_kernel<RR>),                \
@@ -221,6 +242,23 @@ hipError_t launch_flat_mfma_pp(const MfmaParams& P, int r, int grid, size_t lds,
         default: return hipErrorInvalidValue;
     }
 #undef LAUNCH_R
+#ifdef SSMI_STAMP
+    {
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> h((size_t)grid * 48);
+        (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        const char* names[6] = {"wait", "loop", "prefetch", "filter", "sync", "compact"};
+        for (int w : {0, 4}) {
+            fprintf(stderr, "[stamp] wave %d:", w);
+            for (int i = 0; i < 6; ++i) {
+                double sum = 0;
+                for (int b = 0; b < grid; ++b) sum += (double)h[((size_t)b * 8 + w) * 6 + i];
+                fprintf(stderr, " %s %.0f", names[i], sum / grid);
+            }
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     return hipGetLastError();
 }
 

@@ -36,9 +36,11 @@ bool plan_flat_scan(int dtype, int ld, long long nrows, int nq, int k, int num_c
     int blocks_per_cu;
     if (p->qreg) {
         p->nch = nch;
-        p->threads = 256;
-        p->lds = (size_t)4 * kp * sizeof(skey_t);
-        blocks_per_cu = 3;
+        // one block per CU (12 or 8 waves): the same waves in flight as 3 small blocks, but a third of
+        // the per-block partial lists for K3 to merge
+        p->threads = p->r <= 4 ? 768 : 512;
+        p->lds = (size_t)(p->threads / 64) * kp * sizeof(skey_t);
+        blocks_per_cu = (nch == NF) ? 1 : 2;  // shorter rows need fewer registers: two blocks fit
     } else {
         p->nch = 0;
         const size_t qbytes = (size_t)bt * ldq * 4;

@@ -67,7 +67,7 @@ __device__ __forceinline__ int q_lds_index(int elem) {
 // BT: queries per block pass; R: 64*R = per-wave list length; QREG: query in
 // registers (BT == 1, NCH > 0 only).
 template <typename T, int NCH, int BT, int R, bool QREG, bool NT>
-__global__ void __launch_bounds__(QREG ? 256 : 1024) flat_scan_topk_kernel(RowView X, const float* __restrict__ Q, int nq, int k,
+__global__ void __launch_bounds__(QREG ? (R <= 4 ? 768 : 512) : 1024) flat_scan_topk_kernel(RowView X, const float* __restrict__ Q, int nq, int k,
                                       skey_t* __restrict__ partial) {
     constexpr int V = ElemTraits<T>::V;
     static_assert(!QREG || (BT == 1 && NCH > 0), "QREG needs one query and a static row length");
