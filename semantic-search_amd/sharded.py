@@ -60,6 +60,68 @@ def gather_packed(buf: torch.Tensor, B: int, k: int, group=None) -> Tuple[torch.
     return Dg, Ig
 
 
+class _Pipeline:
+    """Three-stream pipeline of a sharded search on one GPU:
+
+        scan stream   local top-k kernels of step i+1, i+2, ...   (never waits for a merge)
+        RCCL stream   all-gather of step i       (torch's process-group stream)
+        merge stream  merge of step i-1
+
+    so that back-to-back searches are bounded by the slowest stage, not by their sum (the
+    collective is latency-bound: 12*B*k bytes per rank).  The caller's current stream only waits
+    for the merge of its own step, so results behave like any other torch op's outputs.
+    Per (B,k) shape a small ring of packed result buffers is reused; a slot is rewritten only
+    after the merge that read it has finished."""
+
+    RING = 4
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.scan = torch.cuda.Stream(device)
+        self.merge = torch.cuda.Stream(device)
+        self.rings = {}
+
+    def slot(self, B: int, k: int, world: int):
+        ring = self.rings.get((B, k))
+        if ring is None:
+            ring = {"next": 0, "slots": []}
+            for _ in range(self.RING):
+                buf, D, I = packed_result_buffers(B, k, self.device)
+                g = torch.empty((world * buf.numel(),), dtype=torch.int64, device=self.device)
+                ring["slots"].append({"buf": buf, "D": D, "I": I, "g": g, "done": None})
+            self.rings[(B, k)] = ring
+        s = ring["slots"][ring["next"]]
+        ring["next"] = (ring["next"] + 1) % self.RING
+        return s
+
+    def run(self, local_search: Callable, merge: Callable, q: torch.Tensor, k: int, group) -> Tuple[torch.Tensor, torch.Tensor]:
+        world = dist.get_world_size(group)
+        B = q.shape[0] if q.dim() == 2 else 1
+        cur = torch.cuda.current_stream(self.device)
+        ready = cur.record_event()                      # q is valid, earlier users of recycled memory are done
+        s = self.slot(B, k, world)
+        self.scan.wait_event(ready)
+        if s["done"] is not None:
+            self.scan.wait_event(s["done"])             # the merge that last read this slot
+        with torch.cuda.stream(self.scan):
+            local_search(q, k, (s["D"], s["I"]))
+            work = dist.all_gather_into_tensor(s["g"], s["buf"], group=group, async_op=True)
+        q.record_stream(self.scan)
+        self.merge.wait_event(ready)
+        with torch.cuda.stream(self.merge):
+            work.wait()                                 # merge stream waits for the collective
+            n = B * k
+            g = s["g"].view(world, -1)
+            Ig = g[:, :n].unflatten(1, (B, k))
+            Dg = g[:, n:].view(torch.float32)[:, :n].unflatten(1, (B, k))
+            D, I = merge(Dg, Ig)
+            s["done"] = self.merge.record_event()
+        D.record_stream(cur)
+        I.record_stream(cur)
+        cur.wait_event(s["done"])
+        return D, I
+
+
 class ShardedFlatIP:
     """Exact inner-product search over a database row-sharded across ranks."""
 
@@ -77,6 +139,8 @@ class ShardedFlatIP:
         self._merge = _merge
         self.row_offset = 0
         self.ntotal = 0
+        self._pipe = None
+        self._force_pipeline = False  # tests: run the gather/merge pipeline even with one rank
 
     def add_local(self, x) -> None:
         self.local.add(x)
@@ -93,8 +157,13 @@ class ShardedFlatIP:
 
     def search(self, q, k: int):
         """q: (B,d) tensor, identical on every rank.  Returns the global (D, I) on every rank."""
-        if self.world == 1:
+        if self.world == 1 and not self._force_pipeline:
             return self.local.search(q, k, id_offset=self.row_offset)
+        if q.is_cuda:
+            if self._pipe is None:
+                self._pipe = _Pipeline(q.device)
+            return self._pipe.run(lambda qq, kk, out: self.local.search(qq, kk, id_offset=self.row_offset, out=out),
+                                  self._merge, q, k, self.group)
         B = q.shape[0] if q.dim() == 2 else 1
         buf, D, I = packed_result_buffers(B, k, q.device)
         self.local.search(q, k, id_offset=self.row_offset, out=(D, I))
@@ -119,6 +188,7 @@ class ShardedIVFFlat:
                                   storage=storage, device=device)
         self._merge = topk_merge
         self.ntotal = 0
+        self._pipe = None
 
     @property
     def nprobe(self) -> int:
@@ -154,8 +224,6 @@ class ShardedIVFFlat:
     def search(self, q, k: int):
         if self.world == 1 or not dist.is_initialized():
             return self.local.search(q, k)
-        B = q.shape[0] if q.dim() == 2 else 1
-        buf, D, I = packed_result_buffers(B, k, q.device)
-        self.local.search(q, k, out=(D, I))
-        Dg, Ig = gather_packed(buf, B, k, self.group)
-        return self._merge(Dg, Ig)
+        if self._pipe is None:
+            self._pipe = _Pipeline(q.device)
+        return self._pipe.run(lambda qq, kk, out: self.local.search(qq, kk, out=out), self._merge, q, k, self.group)
