@@ -131,13 +131,14 @@ def main():
                 "unit": "GB/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
     roof["traffic"] = None
-    try:  # HBM bytes per launch from the committed rocprofv3 PMC pass of this exact workload
+    try:  # HBM bytes per launch from the committed rocprofv3 PMC passes of this exact workload
         prof = json.load(open(os.path.join(ROOT, "profiles", "r01_flat_f32_1M_b1_pmc.json")))
         if (args.n, args.d, args.batch, args.storage, world) == (1_000_000, 4096, 1, "f32", 1):
             for name, v in prof["kernels"].items():
                 if "flat_scan_topk_kernel" in name:
                     roof["traffic"] = v["hbm_bytes_per_launch_corrected"]
-                    roof["traffic_source"] = "profiles/r01_flat_f32_1M_b1_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)"
+                    roof["traffic_source"] = ("profiles/r01_flat_f32_1M_b1_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 "
+                                              "correction + WRITE_SIZE, separate passes; profiles/collect.sh)")
     except Exception:
         pass
     roof["algorithmic_bytes_per_launch"] = algo_bytes
@@ -179,6 +180,15 @@ def main():
                 "mfma_frac_of_2.5PF": flops / (kms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
                 "operand_dtype": "f16 (shadow copy of the f32 rows), f32 accumulate" if args.storage == "f32" else "f16, f32 accumulate",
             }
+        try:  # counter-based MFMA utilisation of the batch-4096 contraction (committed PMC pass)
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_mfma_f16_1M_b4096_pmc.json")))
+            v = next(iter(prof["kernels"].values()))
+            extra["mfma_util_pmc"] = {
+                "value": v["mfma_util"], "kernel_cycles": v["kernel_cycles"],
+                "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE/8), rocprofv3 --pmc, "
+                              "Flat 1M x 4096 f16, batch 4096 (profiles/r01_mfma_f16_1M_b4096_pmc.json)"}
+        except Exception:
+            pass
 
     if rank == 0:
         qps = args.batch * args.steps / elapsed
