@@ -27,6 +27,7 @@
 #include "kernels.h"
 #include "scan_impl.h"
 
+#include "ivf_lists.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -640,7 +641,15 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
     const int ldq = (R.ld + 64 * V - 1) / (64 * V) * 64 * V;
     const size_t lds = std::max((size_t)ldq * 4, (size_t)4 * 64 * r * sizeof(skey_t));
     hipEvent_t* ev = h->ev[h->n_searches % ssmi_index::kEvRing];
-    const int64_t qbatch = std::max<int64_t>(1, std::min<int64_t>(nq, ((size_t)256 << 20) / ((size_t)gx * k * sizeof(skey_t))));
+    // batches whose probes revisit the lists (on average >= 2 probes per list) take the list-major scan
+    int lbt = 0, lthreads = 0;
+    size_t llds = 0;
+    const char* env_lm = getenv("SSMI_IVF_LISTMAJOR");  // tests: 0 = never, 1 = always (when it fits)
+    bool list_major = nq >= 16 && nq * (int64_t)nprobe >= 2 * (int64_t)h->nlist;
+    if (env_lm) list_major = env_lm[0] == '1';
+    list_major = list_major && plan_ivf_list_scan(R.dtype, R.ld, k, &lbt, &lthreads, &llds);
+    const size_t per_q = list_major ? (size_t)nprobe * k * sizeof(skey_t) : (size_t)gx * k * sizeof(skey_t);
+    const int64_t qbatch = std::max<int64_t>(1, std::min<int64_t>(nq, ((size_t)256 << 20) / per_q));
     for (int64_t done = 0; done < nq; done += qbatch) {
         const int nb = (int)std::min(qbatch, nq - done);
         const float* qb = qdev + (size_t)done * R.ld;
@@ -650,6 +659,25 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
         CHECK(ensure_ws(h, 10, (size_t)nb * (nprobe + 1) * 8));
         const RowStore& C = (nb >= 9 && (S->cent16.ld % 64) == 0) ? S->cent16 : S->cent32;
         CHECK(store_search(h, C, nb, qb, nprobe, (float*)h->ws[6], (int64_t*)h->ws[7], 0, s, false));
+        if (list_major) {
+            CHECK(ensure_ws(h, 2, (size_t)nb * nprobe * k * sizeof(skey_t)));
+            CHECK(ensure_ws(h, 11, (size_t)(4 * h->nlist + 2) * 4));
+            CHECK(ensure_ws(h, 12, (size_t)nb * nprobe * 4));
+            IvfListScanArgs A;
+            A.X = R.view(); A.Q = qb; A.Ic = (const int64_t*)h->ws[7]; A.nq = nb; A.nprobe = nprobe; A.nlist = h->nlist;
+            A.k = k; A.page_off = S->d_page_off; A.pages = S->d_pages; A.list_size = S->d_size; A.slot_ids = S->d_slot_ids;
+            A.cnt = (int*)h->ws[11]; A.cursor = A.cnt + h->nlist; A.eoff = A.cursor + h->nlist; A.uoff = A.eoff + h->nlist + 1;
+            A.entries = (int*)h->ws[12]; A.partial = (skey_t*)h->ws[2];
+            A.bt = lbt; A.threads = lthreads; A.lds = llds;
+            A.max_units = (int)std::min<int64_t>((int64_t)nb * nprobe, (int64_t)nb * nprobe / lbt + h->nlist);
+            if (done == 0) HIPCHECK(hipEventRecord(ev[0], s));
+            HIPCHECK(launch_ivf_list_scan(A, R.dtype, s));
+            if (done == 0) HIPCHECK(hipEventRecord(ev[1], s));
+            HIPCHECK(launch_merge_keys((const skey_t*)h->ws[2], nb, nprobe, k, Ddev + (size_t)done * k,
+                                       Idev + (size_t)done * k, id_offset, s));
+            if (done == 0) HIPCHECK(hipEventRecord(ev[2], s));
+            continue;
+        }
         hipLaunchKernelGGL(ivf_plan_kernel, dim3(nb), dim3(256), 0, s, (const int64_t*)h->ws[7], nprobe, S->d_size,
                            (long long*)h->ws[10]);
         HIPCHECK(hipGetLastError());
@@ -682,7 +710,7 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
     h->n_searches++;
     h->timing_valid = true;
     h->timing.last_path = 2;
-    h->timing.last_grid = gx;
+    h->timing.last_grid = list_major ? -lbt : gx;  // negative: list-major scan with that many queries per work item
     h->timing.last_scan_bytes = -1;  // depends on the probed lists; see ssmi_index_get_list_sizes
     h->timing.last_scan_flops = -1;
     return 0;

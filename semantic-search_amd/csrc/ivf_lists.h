@@ -1,0 +1,31 @@
+// ivf_lists.h - launcher of the list-major IVF scan (ivf_lists.hip), called from ivf.hip.
+#pragma once
+#include "common.h"
+
+namespace ssmi {
+
+struct IvfListScanArgs {
+    RowView X;                  // slot store
+    const float* Q;             // (nq, ld) fp32
+    const int64_t* Ic;          // (nq, nprobe) probed lists
+    int nq, nprobe, nlist, k;
+    const int* page_off;        // nlist+1
+    const int* pages;           // CSR payload
+    const int* list_size;       // nlist
+    const uint32_t* slot_ids;
+    // workspaces
+    int* cnt;                   // nlist probes per list, followed by ...
+    int* cursor;                // ... nlist fill cursors (cursor == cnt + nlist: zeroed together)
+    int* eoff;                  // nlist+1
+    int* uoff;                  // nlist+1
+    int* entries;               // nq*nprobe (query*nprobe + probe), grouped by list
+    skey_t* partial;            // [nq*nprobe][k]
+    int bt, threads, max_units;
+    size_t lds;
+};
+
+// queries per work item, block size and LDS bytes for this row length and k; false when a query does not fit LDS
+bool plan_ivf_list_scan(int dtype, int ld, int k, int* bt, int* threads, size_t* lds);
+hipError_t launch_ivf_list_scan(const IvfListScanArgs& A, int dtype, hipStream_t s);
+
+}  // namespace ssmi

@@ -171,3 +171,39 @@ def test_list_sharded_ivf_equals_unsharded(ssa):
             parts.append(sh.local.search(Q, 10))
         D, I = topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
         assert torch.equal(I, Iw) and torch.equal(D, Dw), nprobe
+
+
+@pytest.mark.parametrize("n,d,nlist,storage,nq", [(6000, 256, 40, "f32", 37), (3000, 4096, 16, "f32", 20),
+                                                   (5000, 1024, 64, "f16", 130), (2000, 100, 10, "f32", 16)])
+def test_list_major_batched_scan_matches_oracle_and_per_query_scan(ssa, monkeypatch, n, d, nlist, storage, nq):
+    """K8b (ivf_lists.hip): the list-major scan of a query batch must give exactly what the per-query
+    scan gives, and both must match the oracle fed with the index's own list assignment."""
+    X = clustered_rows(n, d, nlist, 71)
+    C = clustered_rows(nlist, d, nlist, 72)
+    index = make_ivf(ssa, d, nlist, storage)
+    index.set_centroids(C)
+    index.add(X)
+    labels = index.assignments()
+    Xs = r16(X) if storage == "f16" else X
+    Q = clustered_rows(nq, d, nlist, 73)
+    for nprobe in (1, 3, nlist):
+        index.nprobe = nprobe
+        for k in (10, 100, 300):
+            monkeypatch.setenv("SSMI_IVF_LISTMAJOR", "1")
+            D, I = index.search(Q, k)
+            assert index.last_timing()["last_grid"] < 0, "list-major path not taken"
+            monkeypatch.setenv("SSMI_IVF_LISTMAJOR", "0")
+            D2, I2 = index.search(Q, k)
+            assert index.last_timing()["last_grid"] > 0
+            np.testing.assert_array_equal(I, I2)
+            np.testing.assert_array_equal(D, D2)
+            coarse = dict(C_coarse=r16(C), Q_coarse=r16(Q)) if (nq >= 9 and d % 64 == 0) else {}
+            Dr, Ir, _ = ivf_flat.search(Xs, C, labels, Q, k, nprobe, **coarse)
+            if nprobe == nlist or not coarse:
+                ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xs, Q, rtol=1e-5, tie_rtol=1e-5)
+                assert ok, f"nprobe={nprobe} k={k}: {msg}"
+            else:  # fp16 coarse scores may swap two near-tied centroids at the probe boundary
+                agree = np.mean([len(set(a[a >= 0]) & set(b[b >= 0])) / max(1, (b >= 0).sum()) for a, b in zip(I, Ir)])
+                assert agree > 0.97, (nprobe, k, agree)
+    monkeypatch.delenv("SSMI_IVF_LISTMAJOR")
+    index.close()
