@@ -41,7 +41,96 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the batch-1024/4096 MFMA side measurements")
     ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
+    ap.add_argument("--workload", default="flat", choices=["flat", "ivf"],
+                    help="flat = BASELINE configs[1] (the default bench line); ivf = configs[3] (IVF4096, nprobe 32; 1 GPU)")
+    ap.add_argument("--nlist", type=int, default=4096)
+    ap.add_argument("--nprobe", type=int, default=32)
+    ap.add_argument("--ivf-data", default="clustered", choices=["clustered", "iid"],
+                    help="clustered: unit rows around 16384 random centres (sigma 0.6); iid: unit gaussian rows")
     return ap.parse_args()
+
+
+def run_ivf(args):
+    """BASELINE configs[3]: IVF<nlist> nprobe=<nprobe> over n x d f16 rows on one GPU: coarse-quantizer
+    training, add, batch-1 and batch-1000 search, recall@10 against the Flat index over the same rows."""
+    import semantic_search_amd as ssa
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    n, d, nlist, nprobe, k = args.n, args.d, args.nlist, args.nprobe, args.k
+    g = torch.Generator(device=dev).manual_seed(1234)
+    ncl, sigma = 16384, 0.6
+    centres = torch.randn((ncl, d), generator=g, device=dev)
+    centres /= centres.norm(dim=1, keepdim=True)
+
+    def rows(m):
+        x = torch.randn((m, d), generator=g, device=dev) * (sigma / d ** 0.5 if args.ivf_data == "clustered" else 1.0)
+        if args.ivf_data == "clustered":
+            x += centres[torch.randint(0, ncl, (m,), generator=g, device=dev)]
+        return x / x.norm(dim=1, keepdim=True)
+
+    ivf = ssa.IndexIVFFlat(ssa.IndexFlatIP(d, storage="f16"), d, nlist, ssa.METRIC_INNER_PRODUCT, storage="f16")
+    flat = ssa.IndexFlatIP(d, storage="f16")
+    ntrain = min(n, 256 * nlist)
+    xt = rows(ntrain)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ivf.train(xt)
+    torch.cuda.synchronize(); t_train = time.perf_counter() - t0
+    del xt
+    t_add = 0.0
+    for s0 in range(0, n, 65536):
+        x = rows(min(65536, n - s0))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ivf.add(x)
+        t_add += time.perf_counter() - t0
+        flat.add(x)
+    del x
+    ivf.nprobe = nprobe
+    ls = ivf.list_sizes()
+    Q = rows(1000)
+    for i in range(args.warmup):
+        ivf.search(Q[i:i + 1], k)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(args.steps):
+        ivf.search(Q[i % 1000:i % 1000 + 1], k)
+    torch.cuda.synchronize(); elapsed = time.perf_counter() - t0
+    scan_ms = float(np.mean(ivf.scan_times_ms(min(args.steps, 256))))
+    # algorithmic bytes = rows of the probed lists x d x 2 B (SURVEY.md 8d), measured per query: the bench
+    # reads back the prefix-sum total of each of 32 sample queries together with that launch's hipEvent time
+    rows_s, ms_s = [], []
+    for i in range(32):
+        ivf.search(Q[i:i + 1], k)
+        t = ivf.last_timing()
+        rows_s.append(t["last_scan_bytes"] / (d * 2)); ms_s.append(t["last_scan_ms"])
+    probed_rows = float(np.mean(rows_s))
+    algo_bytes = probed_rows * d * 2
+    scan_ms_sample = float(np.mean(ms_s))
+    ivf.search(Q, k)  # warm the batched path
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    Di, Ii = ivf.search(Q, k)
+    torch.cuda.synchronize(); t_b = time.perf_counter() - t0
+    Df, If = flat.search(Q, k)
+    torch.cuda.synchronize()
+    Ii, If = Ii.cpu().numpy(), If.cpu().numpy()
+    recall = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(Ii, If)]))
+    line = {
+        "metric": "queries/sec at k=%d, %d-d (IVF%d nprobe=%d, batch 1)" % (k, d, nlist, nprobe),
+        "value": args.steps / elapsed, "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f16 storage, f32 accumulate", "data": "synthetic (%s)" % args.ivf_data,
+        "config": {"workload": "IVF%d nprobe=%d over %dx%d f16 (BASELINE.json configs[3]), batch 1, k=%d" % (nlist, nprobe, n, d, k),
+                   "rows_total": n, "dim": d, "nlist": nlist, "nprobe": nprobe, "k": k, "train_rows": ntrain},
+        "roofline": {"bound": "hbm", "achieved": algo_bytes / (scan_ms_sample * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": algo_bytes / (scan_ms_sample * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": algo_bytes,
+                     "algorithmic_bytes_note": "mean rows of the probed lists over 32 sample queries (%d; nprobe*N/nlist = %d) x d x 2 B, "
+                                               "over the mean hipEvent time of those launches" % (int(probed_rows), int(nprobe * n / nlist)),
+                     "kernel": "ivf_scan_topk_kernel", "kernel_avg_ms": scan_ms_sample, "kernel_avg_ms_timed_steps": scan_ms},
+        "extra": {"train_s": t_train, "add_s": t_add, "add_vectors_per_s": n / t_add,
+                  "list_sizes": {"min": int(ls.min()), "median": float(np.median(ls)), "max": int(ls.max())},
+                  "batch_1000_qps": 1000 / t_b, "recall_at_%d_vs_flat" % k: recall,
+                  "recall_note": "1000 queries; ground truth = IndexFlatIP (f16 rows) over the same vectors"},
+    }
+    print(json.dumps(line), flush=True)
 
 
 def cpu_baseline(index, d, k, sample_rows, queries):
@@ -69,6 +158,8 @@ def cpu_baseline(index, d, k, sample_rows, queries):
 
 def main():
     args = parse()
+    if args.workload == "ivf":
+        return run_ivf(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

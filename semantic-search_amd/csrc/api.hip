@@ -528,6 +528,14 @@ int ssmi_index_get_timing(const ssmi_index* h, ssmi_timing* out) {
     t.last_scan_ms = a;
     t.last_merge_ms = b;
     t.last_search_ms = a + b;
+    if (t.last_path == 2 && t.last_grid > 0 && h->ws[10]) {
+        // per-query IVF scan: rows probed by the first query of the last search (its prefix-sum total)
+        long long rows = 0;
+        const int nprobe = std::min(h->nprobe, h->nlist);
+        HIPCHECK(hipMemcpy(&rows, (const long long*)h->ws[10] + nprobe, sizeof rows, hipMemcpyDeviceToHost));
+        t.last_scan_bytes = rows * (int64_t)h->rows.d * (int64_t)h->rows.elsize;
+        t.last_scan_flops = 2 * rows * (int64_t)h->rows.d;
+    }
     *out = t;
     return 0;
 }
