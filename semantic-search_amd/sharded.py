@@ -10,6 +10,7 @@ latency-bound; there is no other data-path communication.
 
 The reference has no distributed code; this is new.
 """
+import os
 from typing import Callable, List, Optional, Tuple
 
 import torch
@@ -68,7 +69,11 @@ class _Pipeline:
         merge stream  merge of step i-1
 
     so that back-to-back searches are bounded by the slowest stage, not by their sum (the
-    collective is latency-bound: 12*B*k bytes per rank).  The caller's current stream only waits
+    collective is latency-bound: 12*B*k bytes per rank).  OPT-IN (SSMI_SHARD_PIPELINE=1): measured on this
+    ROCm 7.2 stack (tests/debug_pipeline.py, 125k x 4096 fp32 shard, batch 1) a launch on one stream while
+    a kernel of another stream is running costs the host about that kernel's duration, which makes the
+    three-stream form slower (397 us/step) than the plain one-stream sequence scan -> all-gather -> merge
+    (337 us/step; the scan alone is 305 us), so the one-stream sequence is the default.  The caller's current stream only waits
     for the merge of its own step, so results behave like any other torch op's outputs.
     Per (B,k) shape a small ring of packed result buffers is reused; a slot is rewritten only
     after the merge that read it has finished."""
@@ -140,7 +145,8 @@ class ShardedFlatIP:
         self.row_offset = 0
         self.ntotal = 0
         self._pipe = None
-        self._force_pipeline = False  # tests: run the gather/merge pipeline even with one rank
+        self._force_pipeline = False  # tests: run the gather/merge path even with one rank
+        self._pipelined = os.environ.get("SSMI_SHARD_PIPELINE", "0") == "1"
 
     def add_local(self, x) -> None:
         self.local.add(x)
@@ -159,7 +165,7 @@ class ShardedFlatIP:
         """q: (B,d) tensor, identical on every rank.  Returns the global (D, I) on every rank."""
         if self.world == 1 and not self._force_pipeline:
             return self.local.search(q, k, id_offset=self.row_offset)
-        if q.is_cuda:
+        if q.is_cuda and self._pipelined:
             if self._pipe is None:
                 self._pipe = _Pipeline(q.device)
             return self._pipe.run(lambda qq, kk, out: self.local.search(qq, kk, id_offset=self.row_offset, out=out),

@@ -30,8 +30,9 @@ def one_rank_group():
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("pipelined", [False, True])
 @pytest.mark.parametrize("B,k", [(1, 10), (5, 100), (64, 10)])
-def test_pipelined_search_equals_direct(ssa, one_rank_group, B, k):
+def test_gathered_search_equals_direct(ssa, one_rank_group, B, k, pipelined):
     from semantic_search_amd.sharded import ShardedFlatIP
     n, d, steps = 20000, 512, 24
     X = unit_rows(n, d, 5)
@@ -40,6 +41,7 @@ def test_pipelined_search_equals_direct(ssa, one_rank_group, B, k):
     idx.finalize(device=torch.device("cuda", 0))
     idx.row_offset = 1000  # ids must carry the shard offset through gather and merge
     idx._force_pipeline = True
+    idx._pipelined = pipelined   # default one-stream sequence and the opt-in three-stream pipeline
     Q = torch.from_numpy(unit_rows(steps * B, d, 6)).cuda().view(steps, B, d)
     outs = [idx.search(Q[i], k) for i in range(steps)]  # enqueued back to back, ring of 4 slots reused
     torch.cuda.synchronize()
