@@ -269,6 +269,144 @@ __global__ void __launch_bounds__(256) ivf_scan_topk_kernel(IvfScanParams P) {
     if (wave == 0) top.store(P.partial + ((size_t)q * gridDim.x + blockIdx.x) * P.k, P.k);
 }
 
+// K8, register-query form for rows of NCH KiB (d = 4096: NCH 8 for fp16, 16 for fp32; also 2048, 1024):
+// the query lives in registers as in K1's batch-1 kernel, every chunk of a row is in flight before
+// the first FMA, fp16 rows are taken two at a time (16 KiB in flight per wave), and the page
+// number of a list position is looked up once per page, not once per row.  grid = (gx, nq),
+// blockDim = 64 * nwaves; one k-list per block.
+template <typename T, int NCH, int R>
+__global__ void __launch_bounds__(R <= 4 ? 768 : 512) ivf_scan_qreg_kernel(IvfScanParams P) {
+    constexpr int V = ElemTraits<T>::V;
+    constexpr int ROWS = NCH <= 8 ? 2 : 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = (int)(blockDim.x >> 6);
+    const int q = blockIdx.y;
+    const int ld = P.X.ld;
+    constexpr int row_bytes = NCH * 1024;
+
+    float qreg[NCH][V];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const float4 a = *reinterpret_cast<const float4*>(P.Q + (size_t)q * ld + (c * 64 + lane) * V);
+        qreg[c][0] = a.x; qreg[c][1] = a.y; qreg[c][2] = a.z; qreg[c][3] = a.w;
+        if (V == 8) {
+            const float4 b = *reinterpret_cast<const float4*>(P.Q + (size_t)q * ld + (c * 64 + lane) * V + 4);
+            qreg[c][V - 4] = b.x; qreg[c][V - 3] = b.y; qreg[c][V - 2] = b.z; qreg[c][V - 1] = b.w;
+        }
+    }
+
+    const long long* pf = P.prefix + (size_t)q * (P.nprobe + 1);
+    const int64_t* ic = P.Ic + (size_t)q * P.nprobe;
+    const long long total = pf[P.nprobe];
+    const long long nw = (long long)gridDim.x * nwaves, wv = (long long)blockIdx.x * nwaves + wave;
+    long long r = total * wv / nw;
+    const long long r_hi = total * (wv + 1) / nw;
+    const long long seg_mask = (1ll << P.X.seg_shift) - 1;
+
+    WaveTopK<R> top;
+    top.init();
+    skey_t thr = 0;
+    float thr_s = SSMI_NEG_MAX;
+
+    auto consider = [&](float s, uint32_t id) {
+        if (s >= thr_s) {  // cheap float gate
+            const skey_t key = make_key(s, id);
+            if (key > thr) {
+                top.insert(key);
+                thr = top.kth(P.k);
+                thr_s = (thr == 0) ? SSMI_NEG_MAX : key_score(thr);
+            }
+        }
+    };
+    auto dot = [&](const uint4 (&x)[NCH]) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float xf[V];
+            Unpack<T>::run(x[c], xf);
+#pragma unroll
+            for (int j = 0; j < V; j += 4) {
+                a0 = fmaf(xf[j], qreg[c][j], a0);
+                a1 = fmaf(xf[j + 1], qreg[c][j + 1], a1);
+                a2 = fmaf(xf[j + 2], qreg[c][j + 2], a2);
+                a3 = fmaf(xf[j + 3], qreg[c][j + 3], a3);
+            }
+        }
+        float s = wave_sum((a0 + a1) + (a2 + a3));
+        return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s)));
+    };
+
+    if (r < r_hi) {
+        // The probe table of the query lives in registers, 64 probes at a time: lane i holds the
+        // prefix pf[c0+i], pf[c0+i+1] and the CSR offset of list ic[c0+i].  Finding the list of a
+        // position is then one ballot instead of a chain of dependent global loads.
+        int c0 = -64;
+        long long pf_lo = 0, pf_hi = 0;
+        int po_l = 0;
+        int j = 0;
+        while (r < r_hi) {
+            if (c0 < 0 || r >= __shfl(pf_hi, 63)) {
+                // (re)load the 64-probe window that contains position r
+                do {
+                    c0 += 64;
+                    const int jj = c0 + lane;
+                    const bool in = jj < P.nprobe;
+                    pf_lo = in ? pf[jj] : total;
+                    pf_hi = in ? pf[jj + 1] : total;
+                    po_l = in ? P.page_off[ic[jj]] : 0;
+                } while (c0 + 64 < P.nprobe && r >= __shfl(pf_hi, 63));
+            }
+            // list of position r: the lane whose [pf_lo, pf_hi) contains it (empty lists never match)
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(pf_lo <= r && r < pf_hi);
+            if (hit == 0) break;  // cannot happen: r < total lies in exactly one non-empty list
+            j = __builtin_ctzll(hit);
+            const long long base = (long long)readlane64((skey_t)pf_lo, j);
+            const long long lnext = (long long)readlane64((skey_t)pf_hi, j);
+            const long long lend = lnext < r_hi ? lnext : r_hi;
+            const int* lp = P.pages + __builtin_amdgcn_readlane(po_l, j);
+            while (r < lend) {
+                const long long o = r - base;
+                const int in_page = (int)(o & (kPageRows - 1));
+                long long cnt = kPageRows - in_page;
+                if (cnt > lend - r) cnt = lend - r;
+                const long long slot0 = (long long)lp[o >> kPageShift] * kPageRows + in_page;
+                // a page never straddles a segment (segment sizes are multiples of the page size)
+                const unsigned char* rowp = reinterpret_cast<const unsigned char*>(P.X.segs[slot0 >> P.X.seg_shift]) +
+                                            (size_t)(slot0 & seg_mask) * (size_t)row_bytes + (size_t)lane * 16;
+                // ids of the page's rows: one coalesced load up front instead of a dependent load per
+                // candidate (a wave sees few rows, so most of them enter its still-short list)
+                const int ids_l = (lane < (int)cnt) ? (int)P.slot_ids[slot0 + lane] : 0;
+                int i = 0;
+                if (ROWS == 2) {
+                    for (; i + 2 <= (int)cnt; i += 2) {
+                        uint4 x0[NCH], x1[NCH];
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) x0[c] = load16_nt(rowp + (size_t)i * row_bytes + c * 1024);
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) x1[c] = load16_nt(rowp + (size_t)(i + 1) * row_bytes + c * 1024);
+                        const float s0 = dot(x0);
+                        const float s1 = dot(x1);
+                        consider(s0, (uint32_t)__builtin_amdgcn_readlane(ids_l, i));
+                        consider(s1, (uint32_t)__builtin_amdgcn_readlane(ids_l, i + 1));
+                    }
+                }
+                for (; i < (int)cnt; ++i) {
+                    uint4 x0[NCH];
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) x0[c] = load16_nt(rowp + (size_t)i * row_bytes + c * 1024);
+                    consider(dot(x0), (uint32_t)__builtin_amdgcn_readlane(ids_l, i));
+                }
+                r += cnt;
+            }
+        }
+    }
+    skey_t* lds_keys = reinterpret_cast<skey_t*>(smem);
+    block_merge<R>(top, lds_keys, wave, nwaves);
+    if (wave == 0) top.store(P.partial + ((size_t)q * gridDim.x + blockIdx.x) * P.k, P.k);
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -636,10 +774,20 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
     if (nprobe > kMaxK) return fail("nprobe=%d exceeds the supported maximum %d", nprobe, kMaxK);
     int r = 1;
     while (64 * r < k) r <<= 1;
-    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(1024, ((int64_t)h->num_cu * 6 + nq - 1) / nq));
+    // register-query kernel for rows of 1, 2, 4, 8 or 16 KiB (d = 4096 and its Matryoshka truncations)
+    const int row_kib = (int)(R.row_bytes / 1024);
+    const bool qreg = (R.row_bytes % 1024) == 0 && (row_kib == 1 || row_kib == 2 || row_kib == 4 || row_kib == 8 || row_kib == 16) &&
+                      !getenv("SSMI_IVF_NO_QREG");
+    int qthreads = r <= 4 ? 768 : 512;
+    int qbpc = 1;  // blocks per CU for one query
+    if (const char* e = getenv("SSMI_IVF_QT")) qthreads = atoi(e);
+    if (const char* e = getenv("SSMI_IVF_BPC")) qbpc = atoi(e);
+    const int gx = qreg ? (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)h->num_cu * qbpc, ((int64_t)h->num_cu * 2 * qbpc + nq - 1) / nq))
+                        : (int)std::max<int64_t>(1, std::min<int64_t>(1024, ((int64_t)h->num_cu * 6 + nq - 1) / nq));
     const int V = R.dtype == SSMI_F32 ? 4 : 8;
     const int ldq = (R.ld + 64 * V - 1) / (64 * V) * 64 * V;
-    const size_t lds = std::max((size_t)ldq * 4, (size_t)4 * 64 * r * sizeof(skey_t));
+    const size_t lds = qreg ? (size_t)(qthreads / 64) * 64 * r * sizeof(skey_t)
+                            : std::max((size_t)ldq * 4, (size_t)4 * 64 * r * sizeof(skey_t));
     hipEvent_t* ev = h->ev[h->n_searches % ssmi_index::kEvRing];
     // batches whose probes revisit the lists (on average >= 2 probes per list) take the list-major scan
     int lbt = 0, lthreads = 0;
@@ -695,12 +843,41 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
         hipLaunchKernelGGL((ivf_scan_topk_kernel<TT, RR>), dim3(gx, nb), dim3(256), lds, s, P);                 \
         break;                                                                                                   \
     }
-        if (R.dtype == SSMI_F32) {
+#define IVF_QLAUNCH(TT, NN, RR)                                                                                  \
+    case RR: {                                                                                                   \
+        if (lds > 48 * 1024)                                                                                     \
+            HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_scan_qreg_kernel<TT, NN, RR>),       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+        hipLaunchKernelGGL((ivf_scan_qreg_kernel<TT, NN, RR>), dim3(gx, nb), dim3(qthreads), lds, s, P);        \
+        break;                                                                                                   \
+    }
+#define IVF_QLAUNCH_R(TT, NN)                                                                                    \
+    switch (r) { IVF_QLAUNCH(TT, NN, 1) IVF_QLAUNCH(TT, NN, 2) IVF_QLAUNCH(TT, NN, 4) IVF_QLAUNCH(TT, NN, 8)     \
+                 IVF_QLAUNCH(TT, NN, 16) default: return fail("bad k"); }
+        if (qreg && R.dtype == SSMI_F32) {
+            switch (row_kib) {
+                case 16: IVF_QLAUNCH_R(float, 16) break;
+                case 8: IVF_QLAUNCH_R(float, 8) break;
+                case 4: IVF_QLAUNCH_R(float, 4) break;
+                case 2: IVF_QLAUNCH_R(float, 2) break;
+                default: IVF_QLAUNCH_R(float, 1) break;
+            }
+        } else if (qreg) {
+            switch (row_kib) {
+                case 16: IVF_QLAUNCH_R(__half, 16) break;
+                case 8: IVF_QLAUNCH_R(__half, 8) break;
+                case 4: IVF_QLAUNCH_R(__half, 4) break;
+                case 2: IVF_QLAUNCH_R(__half, 2) break;
+                default: IVF_QLAUNCH_R(__half, 1) break;
+            }
+        } else if (R.dtype == SSMI_F32) {
             switch (r) { IVF_LAUNCH(float, 1) IVF_LAUNCH(float, 2) IVF_LAUNCH(float, 4) IVF_LAUNCH(float, 8) IVF_LAUNCH(float, 16) default: return fail("bad k"); }
         } else {
             switch (r) { IVF_LAUNCH(__half, 1) IVF_LAUNCH(__half, 2) IVF_LAUNCH(__half, 4) IVF_LAUNCH(__half, 8) IVF_LAUNCH(__half, 16) default: return fail("bad k"); }
         }
 #undef IVF_LAUNCH
+#undef IVF_QLAUNCH
+#undef IVF_QLAUNCH_R
         HIPCHECK(hipGetLastError());
         if (done == 0) HIPCHECK(hipEventRecord(ev[1], s));
         HIPCHECK(launch_merge_keys((const skey_t*)h->ws[2], nb, gx, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
