@@ -315,6 +315,34 @@ class SemanticIndex:
         kept = [r for r, k in zip(candidates.results, keep) if k][:top_k]
         return SearchResults(kept, "vector_with_exclusion", "")
 
+    @staticmethod
+    def merge_search_results(results_list: List[SearchResults], top_k: int = DEFAULT_TOP_K,
+                             normalize_scores: bool = True) -> SearchResults:
+        """:635-703 (the consumer of nodes/search_nodes.py:869-881): merge the results of several
+        indexes, optionally min-max normalising each index's scores to [0, 1], deduplicating by file
+        path (highest score wins), best first."""
+        if not results_list:
+            return SearchResults(results=[], query_type="multi_index", query_info="")
+        best: Dict[str, SearchResult] = {}
+        infos = []
+        for sr in results_list:
+            if sr.query_info:
+                infos.append(sr.query_info)
+            if not sr.results:
+                continue
+            lo, span = 0.0, 1.0
+            if normalize_scores:
+                hi, lo = max(r.score for r in sr.results), min(r.score for r in sr.results)
+                span = hi - lo if hi > lo else 1.0
+            for r in sr.results:
+                score = (r.score - lo) / span if normalize_scores else r.score
+                if r.file_path not in best or score > best[r.file_path].score:
+                    best[r.file_path] = SearchResult(file_path=r.file_path, thumbnail_path=r.thumbnail_path,
+                                                     score=score, vector_id=r.vector_id, media_type=r.media_type)
+        merged = sorted(best.values(), key=lambda x: x.score, reverse=True)[:top_k]
+        return SearchResults(results=merged, query_type="multi_index",
+                             query_info=" + ".join(infos) if infos else "multi-index search")
+
     # -- maintenance --------------------------------------------------------------
     def _new_config(self, new_type: IndexType) -> IndexConfig:
         p = self._config.get("index_params", {})

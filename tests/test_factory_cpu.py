@@ -88,3 +88,21 @@ def test_out_of_scope_types_fail_loudly(ssa):
             F.create_index(C(t, 64))
     with pytest.raises(ValueError):
         F.create_index(C("bogus", 64))
+
+
+def test_merge_search_results_normalises_dedups_and_sorts(ssa):
+    """Mirror of SemanticIndex.merge_search_results (reference core/index_manager.py:635-703)."""
+    from semantic_search_amd.index_manager import SearchResult, SearchResults, SemanticIndex
+    a = SearchResults([SearchResult("x.jpg", "tx", 0.9, 1), SearchResult("y.jpg", "ty", 0.5, 2)], "text", "cats")
+    b = SearchResults([SearchResult("y.jpg", "ty", 0.30, 7), SearchResult("z.jpg", "tz", 0.10, 8),
+                       SearchResult("w.jpg", "tw", 0.20, 9)], "text", "dogs")
+    m = SemanticIndex.merge_search_results([a, b], top_k=3)
+    assert m.query_type == "multi_index" and m.query_info == "cats + dogs"
+    # per-index min-max: a -> x 1.0, y 0.0; b -> y 1.0, w 0.5, z 0.0; y keeps its best (1.0, id 7)
+    assert [(r.file_path, round(r.score, 6)) for r in m] == [("x.jpg", 1.0), ("y.jpg", 1.0), ("w.jpg", 0.5)]
+    assert m[1].vector_id == 7
+    raw = SemanticIndex.merge_search_results([a, b], top_k=10, normalize_scores=False)
+    assert [r.file_path for r in raw] == ["x.jpg", "y.jpg", "w.jpg", "z.jpg"] and raw[1].score == 0.5
+    assert len(SemanticIndex.merge_search_results([])) == 0
+    one = SearchResults([SearchResult("q.jpg", "t", 0.4, 3)], "text", "")   # single score: range falls back to 1.0
+    assert SemanticIndex.merge_search_results([one])[0].score == 0.0
