@@ -93,7 +93,9 @@ class _Pipeline:
             for _ in range(self.RING):
                 buf, D, I = packed_result_buffers(B, k, self.device)
                 g = torch.empty((world * buf.numel(),), dtype=torch.int64, device=self.device)
-                ring["slots"].append({"buf": buf, "D": D, "I": I, "g": g, "done": None})
+                # events are created once per slot and re-recorded: destroying a still-pending event blocks the host
+                ring["slots"].append({"buf": buf, "D": D, "I": I, "g": g, "used": False,
+                                      "ready": torch.cuda.Event(), "done": torch.cuda.Event()})
             self.rings[(B, k)] = ring
         s = ring["slots"][ring["next"]]
         ring["next"] = (ring["next"] + 1) % self.RING
@@ -103,11 +105,12 @@ class _Pipeline:
         world = dist.get_world_size(group)
         B = q.shape[0] if q.dim() == 2 else 1
         cur = torch.cuda.current_stream(self.device)
-        ready = cur.record_event()                      # q is valid, earlier users of recycled memory are done
         s = self.slot(B, k, world)
-        self.scan.wait_event(ready)
-        if s["done"] is not None:
+        if s["used"]:
             self.scan.wait_event(s["done"])             # the merge that last read this slot
+        ready = s["ready"]
+        ready.record(cur)                               # q is valid, earlier users of recycled memory are done
+        self.scan.wait_event(ready)
         with torch.cuda.stream(self.scan):
             local_search(q, k, (s["D"], s["I"]))
             work = dist.all_gather_into_tensor(s["g"], s["buf"], group=group, async_op=True)
@@ -120,7 +123,8 @@ class _Pipeline:
             Ig = g[:, :n].unflatten(1, (B, k))
             Dg = g[:, n:].view(torch.float32)[:, :n].unflatten(1, (B, k))
             D, I = merge(Dg, Ig)
-            s["done"] = self.merge.record_event()
+            s["done"].record(self.merge)
+            s["used"] = True
         D.record_stream(cur)
         I.record_stream(cur)
         cur.wait_event(s["done"])
