@@ -8,8 +8,8 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 OUT=gpurun_out
 BENCH="python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline"
-MFMA="python3 tests/prof_mfma.py 1000000 4096 4096 10"
-IVF="python3 tests/prof_ivf.py 2000000 4096 1024 16"
+MFMA="python3 tools/prof_mfma.py 1000000 4096 4096 10"
+IVF="python3 tools/prof_ivf.py 2000000 4096 1024 16"
 
 echo "== kernel-trace stats: bench"
 timeout -s KILL 300 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/prof_${TAG}_stats -o bench -- $BENCH > $OUT/prof_${TAG}_stats.log 2>&1

@@ -82,8 +82,8 @@ pmc("flat_f32_1M_b1", [f"prof_{tag}_pmc_FETCH_SIZE", f"prof_{tag}_pmc_WRITE_SIZE
     "Flat IP 1000000x4096 f32: batch 1 k=10 (flat_scan_topk_kernel) and the batch 1024/4096 side runs (flat_mfma_pp_kernel on the f16 shadow)",
     ["flat_scan_topk_kernel", "flat_mfma_pp_kernel", "merge_keys_kernel"])
 pmc("mfma_f16_1M_b4096", [f"prof_{tag}_mfma_pmc_sq", f"prof_{tag}_mfma_pmc_lds", f"prof_{tag}_mfma_pmc_FETCH_SIZE"],
-    "rocprofv3 --pmc <group> (separate runs) -- python3 tests/prof_mfma.py 1000000 4096 4096 10",
+    "rocprofv3 --pmc <group> (separate runs) -- python3 tools/prof_mfma.py 1000000 4096 4096 10",
     "Flat IP 1000000x4096 f16, batch 4096, k=10", ["flat_mfma_pp_kernel"])
 pmc("ivf_f16_2M_b1", [f"prof_{tag}_ivf_pmc_FETCH_SIZE", f"prof_{tag}_ivf_pmc_WRITE_SIZE"],
-    "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate runs) -- python3 tests/prof_ivf.py 2000000 4096 1024 16",
+    "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate runs) -- python3 tools/prof_ivf.py 2000000 4096 1024 16",
     "IVF1024 nprobe=16 over 2000000x4096 f16, batch 1, k=10", ["ivf_scan_topk_kernel", "flat_scan_topk_kernel", "ivf_plan_kernel"])

@@ -70,9 +70,9 @@ class _Pipeline:
 
     so that back-to-back searches are bounded by the slowest stage, not by their sum (the
     collective is latency-bound: 12*B*k bytes per rank).  OPT-IN (SSMI_SHARD_PIPELINE=1): measured on this
-    ROCm 7.2 stack (tests/debug_pipeline.py, 125k x 4096 fp32 shard, batch 1) a launch on one stream while
-    a kernel of another stream is running costs the host about that kernel's duration, which makes the
-    three-stream form slower (397 us/step) than the plain one-stream sequence scan -> all-gather -> merge
+    ROCm 7.2 stack (tools/debug_pipeline.py, 125k x 4096 fp32 shard, batch 1) the torch-level
+    three-stream form costs the host ~290 us per step (raw HIP launches and event waits across streams cost 2-14 us
+    under the same load, so the cost is in the torch/RCCL stream plumbing, not in HIP), which makes it slower (397 us/step) than the plain one-stream sequence scan -> all-gather -> merge
     (337 us/step; the scan alone is 305 us), so the one-stream sequence is the default.  The caller's current stream only waits
     for the merge of its own step, so results behave like any other torch op's outputs.
     Per (B,k) shape a small ring of packed result buffers is reused; a slot is rewritten only
