@@ -214,3 +214,35 @@ def test_large_random_unit_matches_oracle_on_readback(ssa):
     assert np.allclose(np.linalg.norm(X, axis=1), 1.0, atol=1e-4)
     assert abs(float(X.mean())) < 1e-3 and abs(float(X.std()) * np.sqrt(d) - 1.0) < 0.02
     _check(index, X, unit_rows(2, d, 4321), 10)
+
+
+def test_distinct_indexes_from_distinct_threads(ssa):
+    """The boundary contract (include/ssmi.h): calls on ONE handle are serialised by the caller (the
+    reference holds a per-index RLock), distinct handles may be used from distinct threads (ComfyUI worker
+    threads, global index cache at core/index_manager.py:1481-1504); ctypes drops the GIL during calls."""
+    import threading
+    d, k = 512, 10
+    data = [(unit_rows(6000 + 500 * t, d, 100 + t), unit_rows(3, d, 200 + t)) for t in range(4)]
+    expected = [flat_ip.search(X, Q, k) for X, Q in data]
+    errors = []
+
+    def worker(t):
+        try:
+            X, Q = data[t]
+            index = ssa.IndexFlatIP(d, storage="f32")
+            for s in range(0, len(X), 1000):
+                index.add(X[s:s + 1000])
+            for _ in range(25):
+                D, I = index.search(Q, k)
+                ok, msg, _ = flat_ip.check_against(D, I, expected[t][0], expected[t][1], X, Q, rtol=1e-5, tie_rtol=1e-5)
+                assert ok, msg
+            index.close()
+        except Exception as e:  # surfaced in the main thread below
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
