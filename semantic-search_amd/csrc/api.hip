@@ -326,9 +326,12 @@ int ssmi_index_train(ssmi_index* h, int64_t n, const float* x, int mem_kind) {
 }
 
 // ------------------------------------------------------------------ search
-static int mfma_min_batch() {
+// Smallest query batch that takes the MFMA path.  fp16 rows: 5 (the register-FMA scan is VALU-bound beyond 4
+// queries, the 128-query MFMA stream is HBM-bound); fp32 rows: 9 (below that the exact fp32 scan, above it the
+// fp16 shadow copy).
+static int mfma_min_batch(int dtype) {
     const char* e = getenv("SSMI_MFMA_MIN_B");
-    int v = e ? atoi(e) : 9;
+    int v = e ? atoi(e) : (dtype == SSMI_F16 ? 5 : 9);
     return v < 1 ? 1 : v;
 }
 
@@ -368,10 +371,10 @@ namespace ssmi {
 // record = false: no events/timing (used for the IVF coarse quantizer).
 int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev /*(nq,ld)*/, int k, float* Ddev,
                  int64_t* Idev, int64_t id_offset, hipStream_t s, bool record) {
-    if (R.dtype == SSMI_F16 && (R.ld % 64) == 0 && nq >= mfma_min_batch())
+    if (R.dtype == SSMI_F16 && (R.ld % 64) == 0 && nq >= mfma_min_batch(SSMI_F16))
         return store_search_mfma(h, R, nq, qdev, k, Ddev, Idev, id_offset, s, record);
     if (&R == &h->rows && h->kind == SSMI_KIND_FLAT && R.dtype == SSMI_F32 && (R.ld % 64) == 0 &&
-        nq >= mfma_min_batch() && !getenv("SSMI_NO_SHADOW")) {
+        nq >= mfma_min_batch(SSMI_F32) && !getenv("SSMI_NO_SHADOW")) {
         // bring the fp16 shadow up to date, then run the MFMA contraction on it
         if (!h->has_shadow) { CHECK(h->shadow16.init(R.d, SSMI_F16)); h->has_shadow = true; }
         RowStore& S = h->shadow16;

@@ -24,6 +24,7 @@
 // query) and whenever a buffer is half full.  At the end of the slice the k-list
 // IS the per-slice partial result that K3 (merge.hip) merges across slices.
 #include "mfma_common.h"
+#include <cstdlib>
 
 namespace ssmi {
 
@@ -45,7 +46,9 @@ bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_c
     p->grid = p->nqt * p->nslices;
     p->qh_bytes = (size_t)p->nqt * TN * ld * 2;
     p->cand_bytes = (size_t)p->grid * TN * CAND_CAP * sizeof(skey_t);
-    p->lds = 4 * TILE_BYTES + EPI_LDS_BYTES;
+    const char* env_n = getenv("SSMI_MFMA_NARROW");
+    p->narrow = nq <= N128_TN && !(env_n && env_n[0] == '0');
+    p->lds = p->narrow ? (size_t)N128_RING * N128_SLOT + 3 * N128_TN * 4 + 16 : (size_t)4 * TILE_BYTES + EPI_LDS_BYTES;
     return true;
 }
 
@@ -59,6 +62,7 @@ hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, con
     P.rows_per_slice = p.rows_per_slice; P.partial = partial; P.cand = (skey_t*)cand;
     int r = 1;
     while (64 * r < k) r <<= 1;
+    if (p.narrow) return launch_flat_mfma_n128(P, r, p.grid, p.lds, s);
     return launch_flat_mfma_pp(P, r, p.grid, p.lds, s);
 }
 

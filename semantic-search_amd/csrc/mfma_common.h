@@ -109,33 +109,37 @@ __device__ __forceinline__ float vmax2(float a, float b) {
 // wave-uniform branch; a column that does is searched accumulator by accumulator.
 // FULL = false adds the row-range test for the last, partial row tile of a slice (its padding
 // rows repeat the last valid row).
-template <bool FULL>
-__device__ __forceinline__ void filter_tile(const f32x4_t (&acc)[8][4], int wm, int wn, int frow, int fq, long long row0,
-                                            int rows_valid, skey_t* cand, const float* thr_l, unsigned* cnt_l,
-                                            unsigned* flag_l) {
+template <int MT, int NT, bool FULL>
+__device__ __forceinline__ void filter_tile(const f32x4_t (&acc)[MT][NT], int row_base, int q_base, int frow, int fq,
+                                            long long row0, int rows_valid, skey_t* cand, const float* thr_l,
+                                            unsigned* cnt_l, unsigned* flag_l) {
+    // acc[m][n]: rows row_base + m*16 + fq*4 + i of the row tile, query q_base + n*16 + frow of the query tile.
     // keep the per-column LDS/global addresses out of the main loop's register budget: they are
     // recomputed here per row tile instead of being hoisted (and spilled) by the compiler
     asm volatile("" : "+v"(frow));
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int ql = wn * 64 + n * 16 + frow;
+    for (int n = 0; n < NT; ++n) {
+        const int ql = q_base + n * 16 + frow;
         const float thr = thr_l[ql];
-        float mm[8];
+        float mm[MT];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) mm[m] = vmax2(vmax3(acc[m][n][0], acc[m][n][1], acc[m][n][2]), acc[m][n][3]);
-        const float mx = vmax3(vmax3(mm[0], mm[1], mm[2]), vmax3(mm[3], mm[4], mm[5]), vmax2(mm[6], mm[7]));
+        for (int m = 0; m < MT; ++m) mm[m] = vmax2(vmax3(acc[m][n][0], acc[m][n][1], acc[m][n][2]), acc[m][n][3]);
+        float mx = mm[0];
+#pragma unroll
+        for (int m = 1; m + 1 < MT; m += 2) mx = vmax3(mx, mm[m], mm[m + 1]);
+        if ((MT & 1) == 0) mx = vmax2(mx, mm[MT - 1]);
         if (__builtin_amdgcn_ballot_w64(mx >= thr) == 0) continue;
         // survivors in this column: count them per lane, reserve their slots with ONE LDS atomic per
         // lane, then store them (accumulators without a survivor in any lane are skipped wave-wide)
-        unsigned long long hot[8];
+        unsigned long long hot[MT];
         unsigned c = 0;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < MT; ++m) {
             hot[m] = __builtin_amdgcn_ballot_w64(mm[m] >= thr);
             if (hot[m] == 0) continue;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                c += (acc[m][n][i] >= thr && (FULL || wm * 128 + m * 16 + fq * 4 + i < rows_valid)) ? 1u : 0u;
+                c += (acc[m][n][i] >= thr && (FULL || row_base + m * 16 + fq * 4 + i < rows_valid)) ? 1u : 0u;
         }
         unsigned pos = 0;
         if (c) {
@@ -144,12 +148,12 @@ __device__ __forceinline__ void filter_tile(const f32x4_t (&acc)[8][4], int wm, 
         }
         skey_t* cq = cand + (size_t)ql * CAND_CAP;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < MT; ++m) {
             if (hot[m] == 0) continue;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float s = acc[m][n][i];
-                const int rr = wm * 128 + m * 16 + fq * 4 + i;
+                const int rr = row_base + m * 16 + fq * 4 + i;
                 if (s >= thr && (FULL || rr < rows_valid)) {
                     if (pos < (unsigned)CAND_CAP) cq[pos] = make_key(s, (uint32_t)(row0 + rr));
                     ++pos;
@@ -159,7 +163,10 @@ __device__ __forceinline__ void filter_tile(const f32x4_t (&acc)[8][4], int wm, 
     }
 }
 
-// ping-pong variant (mfma_pp.hip)
+// ping-pong kernel, 256-query tile (mfma_pp.hip)
 hipError_t launch_flat_mfma_pp(const MfmaParams& P, int r, int grid, size_t lds, hipStream_t s);
+// streaming kernel, 128-query tile, for batches up to 128 (mfma_n128.hip)
+hipError_t launch_flat_mfma_n128(const MfmaParams& P, int r, int grid, size_t lds, hipStream_t s);
+static constexpr int N128_RING = 6, N128_SLOT = 24 * 1024, N128_TN = 128;
 
 }  // namespace ssmi

@@ -195,8 +195,8 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
         STAMP(2)
         // ---- epilogue: threshold filter, survivors -> candidate buffers ----
         const long long left = r_end - row0;
-        if (left >= TM) filter_tile<true>(acc, wm, wn, frow, fq, row0, TM, cand, thr_l, cnt_l, flag_l);
-        else filter_tile<false>(acc, wm, wn, frow, fq, row0, (int)left, cand, thr_l, cnt_l, flag_l);
+        if (left >= TM) filter_tile<8, 4, true>(acc, wm * 128, wn * 64, frow, fq, row0, TM, cand, thr_l, cnt_l, flag_l);
+        else filter_tile<8, 4, false>(acc, wm * 128, wn * 64, frow, fq, row0, (int)left, cand, thr_l, cnt_l, flag_l);
         STAMP(3)
         __syncthreads();
         STAMP(4)

@@ -70,16 +70,18 @@ def test_flat_f32_large_batch_exact_path_without_shadow(ssa, monkeypatch):
     assert index.last_timing()["last_path"] == 0
 
 
-@pytest.mark.parametrize("n,d,nq,k", [(10000, 4096, 1, 10), (10000, 4096, 8, 10), (3000, 4096, 2, 100),
-                                      (2000, 2048, 1, 10), (777, 72, 3, 10)])
+@pytest.mark.parametrize("n,d,nq,k", [(10000, 4096, 1, 10), (10000, 4096, 4, 10), (3000, 4096, 2, 100),
+                                      (2000, 2048, 1, 10), (777, 72, 3, 10), (5000, 72, 8, 10)])
 def test_flat_f16_storage_matches_oracle_on_rounded_rows(ssa, n, d, nq, k):
-    """fp16 storage: the kernel must be exact against the oracle run on the fp16-rounded rows."""
+    """fp16 storage, streaming scan (up to 4 queries, or any batch when d is not a multiple of 64): the kernel
+    must be exact against the oracle run on the fp16-rounded rows with fp32 queries."""
     X = unit_rows(n, d, 1234)
     Xh = X.astype(np.float16).astype(np.float32)
     Q = unit_rows(nq, d, 4321)
     index = ssa.IndexFlatIP(d, storage="f16")
     index.add(X)
     _check(index, Xh, Q, k)
+    assert index.last_timing()["last_path"] == 0
     # and reconstruct returns exactly the rounded rows
     np.testing.assert_array_equal(index.reconstruct_batch([0, n // 2, n - 1]), Xh[[0, n // 2, n - 1]])
     index.close()

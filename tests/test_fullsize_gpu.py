@@ -84,8 +84,8 @@ def test_flat_10m_f16_batch4096_k100_configs2(ssa):
     np.testing.assert_allclose(D[:len(planted), 0], 1.0, atol=2e-3)   # fp16-rounded rows are not exactly unit norm
     Dt2, It2 = index.search(Qt, k)                                     # idempotence (atomics only order buffers)
     assert torch.equal(It2, It) and torch.equal(Dt2, Dt)
-    # K1 (fp32 queries, exact fp32 products of the stored fp16 rows) on 8 of the queries
-    sel = np.array([0, 1, 2, 3, 4, 5, 100, 4095])
+    # K1 (fp32 queries, exact fp32 products of the stored fp16 rows) on 4 of the queries
+    sel = np.array([0, 3, 100, 4095])
     D1, I1 = index.search(Q[sel], k)
     assert index.last_timing()["last_path"] == 0
     np.testing.assert_allclose(D[sel], D1, rtol=1e-3, atol=1e-4)
