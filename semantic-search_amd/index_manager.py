@@ -181,6 +181,14 @@ class SemanticIndex:
         self._lock = threading.RLock()                          # :175
         self._training_buffer: List[np.ndarray] = []            # :178-179
         self._training_buffer_size = 0
+        # Additive: in the reference the vectors buffered for IVF training live only in
+        # memory (:288-289) although their metadata rows already exist, so they are lost when the process exits
+        # before training; here save() persists them next to vectors.faiss and they are restored on load.
+        self.training_buffer_path = self.index_path / "training_buffer.npy"
+        if self.training_buffer_path.exists() and IndexFactory.needs_training(self._faiss_index):
+            buf = np.load(self.training_buffer_path, allow_pickle=False)
+            if buf.ndim == 2 and buf.shape[1] == self.embedding_dim and len(buf):
+                self._training_buffer, self._training_buffer_size = [np.ascontiguousarray(buf, dtype=np.float32)], len(buf)
 
     # -- load / create / save -------------------------------------------------
     def _load_or_create_faiss(self) -> None:
@@ -218,6 +226,10 @@ class SemanticIndex:
         with self._lock:
             faiss.write_index(self._faiss_index, str(self.faiss_path))
             self._save_config()
+            if self._training_buffer_size:
+                np.save(self.training_buffer_path, np.vstack(self._training_buffer))
+            elif self.training_buffer_path.exists():
+                self.training_buffer_path.unlink()
 
     # -- add --------------------------------------------------------------------
     def add_vectors(self, vectors: np.ndarray, file_paths: List[str], thumbnail_paths: List[str],

@@ -146,3 +146,27 @@ def test_semantic_index_lifecycle(ssa, tmp_path):
     vid = si2.add_document_vector(X[0], "/doc/a.pdf#1", "/th/a.jpg")
     assert vid == 1198
     si2.close(); si.db.close()
+
+
+def test_training_buffer_survives_save_and_reload(ssa, tmp_path):
+    """Additive over the reference: vectors buffered for IVF training are persisted by
+    save() and restored on load, instead of being lost with the process (core/index_manager.py:288-289)."""
+    from semantic_search_amd.index_manager import SemanticIndex
+    d = 64
+    X = unit_rows(1100, d, 19)
+    si = SemanticIndex("buf", embedding_dim=d, index_type="ivf_flat", base_path=tmp_path)
+    ids = si.add_vectors(X[:600], [f"/i/{i}" for i in range(600)], [""] * 600, [(0.0, 0)] * 600)
+    assert ids == list(range(600)) and si._faiss_index.ntotal == 0 and si._training_buffer_size == 600
+    si.save()
+    assert si.training_buffer_path.exists()
+    si.close()
+    si2 = SemanticIndex("buf", embedding_dim=d, index_type="ivf_flat", base_path=tmp_path)
+    assert si2._training_buffer_size == 600 and not si2._faiss_index.is_trained
+    ids = si2.add_vectors(X[600:], [f"/i/{i}" for i in range(600, 1100)], [""] * 500, [(0.0, 0)] * 500)
+    assert ids == list(range(600, 1100))
+    assert si2._faiss_index.is_trained and si2._faiss_index.ntotal == 1100 and si2._training_buffer_size == 0
+    si2._faiss_index.nprobe = 100
+    assert si2.search(X[5], top_k=1)[0].vector_id == 5        # a vector buffered before the restart is searchable
+    si2.save()
+    assert not si2.training_buffer_path.exists()
+    si2.close()
