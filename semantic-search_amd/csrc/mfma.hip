@@ -62,7 +62,11 @@ hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, con
     P.rows_per_slice = p.rows_per_slice; P.partial = partial; P.cand = (skey_t*)cand;
     int r = 1;
     while (64 * r < k) r <<= 1;
-    if (p.narrow) return launch_flat_mfma_n128(P, r, p.grid, p.lds, s);
+    if (p.narrow) {
+        const char* env_r = getenv("SSMI_MFMA_R128");
+        if (mfma_r128_supported(X.ld, k) && !(env_r && env_r[0] == '0')) return launch_flat_mfma_r128(P, r, p.grid, s);
+        return launch_flat_mfma_n128(P, r, p.grid, p.lds, s);
+    }
     return launch_flat_mfma_pp(P, r, p.grid, p.lds, s);
 }
 

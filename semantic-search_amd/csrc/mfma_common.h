@@ -167,6 +167,9 @@ __device__ __forceinline__ void filter_tile(const f32x4_t (&acc)[MT][NT], int ro
 hipError_t launch_flat_mfma_pp(const MfmaParams& P, int r, int grid, size_t lds, hipStream_t s);
 // streaming kernel, 128-query tile, for batches up to 128 (mfma_n128.hip)
 hipError_t launch_flat_mfma_n128(const MfmaParams& P, int r, int grid, size_t lds, hipStream_t s);
+// register-streaming kernel, 128-query tile, rows of a multiple of 512 elements (mfma_r128.hip)
+hipError_t launch_flat_mfma_r128(const MfmaParams& P, int r, int grid, hipStream_t s);
+bool mfma_r128_supported(int ld, int k);
 static constexpr int N128_RING = 6, N128_SLOT = 24 * 1024, N128_TN = 128;
 
 }  // namespace ssmi

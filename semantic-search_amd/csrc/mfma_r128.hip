@@ -1,0 +1,226 @@
+// mfma_r128.hip - K2r: Flat search of a medium query batch (5..128 queries, fp16 rows whose
+// length is a multiple of 512) as an HBM-bound MFMA stream with the DATABASE ROWS STREAMED STRAIGHT
+// INTO REGISTERS.
+//
+// mfma_n128.hip stages the rows through a ring of LDS slots, which caps the bytes in flight per
+// CU at 64-80 KiB and the bandwidth at 4.4 TB/s.  Here only the query slabs live in LDS:
+//
+//   workgroup = 8 waves, row tile = 256 rows, wave w owns rows 32w .. 32w+31 (two 16-row MFMA
+//   blocks) and ALL 128 queries: 2 x 8 accumulators of 16x16 (v_mfma_f32_16x16x32_f16);
+//   K is walked in steps of 64.  The A fragments of a step (lane (r, q): 16 B of row r at k + 8q) are
+//   global_load_dwordx4 in exactly the MFMA operand layout, issued PD steps ahead into a register
+//   ring (PD x 16 VGPRs): with PD = 8 that is 32 KiB in flight per wave, 256 KiB per CU, and
+//   no barrier or LDS traffic for the rows at all; the stream runs across row-tile boundaries.
+//   The B fragments come from a ring of PD+1 LDS slots of 16 KiB (128 queries x 64 k, stored as two
+//   swizzled 64-byte-row slabs like mfma_pp.hip), filled by LDS-DMA PD steps ahead as well (the
+//   vmcnt counter is in order, so both streams must run equally far ahead); one barrier per step
+//   publishes a query slab.
+//
+// Threshold filter and list compaction are those of mfma_pp.hip (mfma_common.h); the candidate stores
+// are drained (vmcnt(0)) only in front of a compaction, so the row stream keeps flowing through the
+// end of a row tile.
+#include "mfma_common.h"
+
+namespace ssmi {
+
+static constexpr int RQ_SLOT = 16 * 1024;  // one query slab: 2 k-halves x (128 queries x 64 B)
+
+// NT: 16-query blocks actually scored (1, 4 or 8): a batch of <= 16 queries costs 4 MFMAs and 2 fragment reads
+// per step and wave instead of 32 and 16, and leaves the registers for a ring of 8 steps.
+template <int R, int PD, int NT>
+__global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
+    constexpr int QD = PD + 1;          // query ring slots
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* thr_l = reinterpret_cast<float*>(smem + QD * RQ_SLOT);
+    unsigned* cnt_l = reinterpret_cast<unsigned*>(thr_l + N128_TN);
+    unsigned* kept_l = cnt_l + N128_TN;
+    unsigned* flag_l = kept_l + N128_TN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int slice = blockIdx.x;
+    const long long r_begin = (long long)slice * P.rows_per_slice;
+    const long long r_end = (r_begin + P.rows_per_slice < P.X.nrows) ? (r_begin + P.rows_per_slice) : P.X.nrows;
+    skey_t* cand = P.cand + (size_t)blockIdx.x * N128_TN * CAND_CAP;
+
+    if (tid < N128_TN) {
+        thr_l[tid] = (tid < P.nq) ? SSMI_NEG_MAX : __builtin_inff();
+        cnt_l[tid] = 0;
+        kept_l[tid] = 0;
+    }
+    if (tid == 0) *flag_l = 0;
+    __syncthreads();
+    if (r_begin >= r_end) return;
+
+    const int ld = P.X.ld;
+    const int ns = ld / 64;  // steps per row tile (a multiple of PD: the host checks ld % 512 == 0)
+    const int ntiles = (int)((r_end - r_begin + TM - 1) / TM);
+    const int total = ntiles * ns;
+    const long long seg_mask = (1ll << P.X.seg_shift) - 1;
+
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fch = (fq ^ ((-(frow >> 2)) & 3)) * 16;
+    const int b_off = frow * 64 + fch;  // + kh * 8192 + n * 1024
+
+    // query slab DMA: wave w brings queries 16w .. 16w+15 of both k-halves (2 pieces of 1 KiB per step)
+    const int qrow = wave * 16 + (lane >> 2);
+    const unsigned char* qsrc = reinterpret_cast<const unsigned char*>(P.Qh) + (size_t)qrow * ld * 2 +
+                                ((lane & 3) ^ ((-(qrow >> 2)) & 3)) * 16;
+    auto issue_q = [&](int g /*global step*/) {
+        const int s = g % ns;
+        unsigned char* dst = smem + (g % QD) * RQ_SLOT + wave * 1024;
+        if (wave < NT) {  // queries 16w .. 16w+15 are scored at all
+            GLDS16(qsrc + (size_t)s * 128, dst);
+            GLDS16(qsrc + (size_t)s * 128 + 64, dst + 8192);
+        }
+    };
+    // row base of this lane's two 16-row blocks in row tile `t` (padding rows repeat the last valid row)
+    auto tile_rows = [&](int t, const unsigned char* (&base)[2]) {
+        const long long t0 = r_begin + (long long)t * TM;
+        const unsigned char* segbase = reinterpret_cast<const unsigned char*>(P.X.segs[t0 >> P.X.seg_shift]);
+        const long long left = r_end - t0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            long long rr = wave * 32 + m * 16 + frow;
+            if (rr >= left) rr = left - 1;
+            base[m] = segbase + (size_t)((t0 & seg_mask) + rr) * (size_t)ld * 2 + fq * 16;
+        }
+    };
+
+    half8_t areg[PD][2][2];  // [ring slot][16-row block][k-half]
+    const unsigned char* abase[2];
+    // The row loads are issued as opaque instructions: the compiler's wait-count pass cannot count loads
+    // across this loop nest and would put s_waitcnt vmcnt(0) in front of every use, which turns the register
+    // ring into a blocking load.  Completion is enforced by the counted waits below, which take the ring
+    // slot's registers as in/out operands so that no use can be scheduled above them.
+    auto load_a = [&](half8_t (&dst)[2][2], const unsigned char* const (&base)[2], int s) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                const unsigned char* ptr = base[m] + (size_t)s * 128 + kh * 64;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[m][kh]) : "v"(ptr) : "memory");
+            }
+    };
+
+    // pipeline fill: steps 0 .. PD-1 (all in the first row tile: ns >= PD)
+    tile_rows(0, abase);
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+        issue_q(u);
+        load_a(areg[u], abase, u);
+    }
+
+    f32x4_t acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    unsigned tiles_done = 0;
+    int g = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const long long row0 = r_begin + (long long)t * TM;
+        const unsigned char* nbase[2] = {abase[0], abase[1]};
+        if (t + 1 < ntiles) tile_rows(t + 1, nbase);
+        for (int s0 = 0; s0 < ns; s0 += PD) {
+            const bool refill_next_tile = (s0 + PD >= ns);
+#pragma unroll
+            for (int u = 0; u < PD; ++u, ++g) {
+                // this wave's loads and DMA of step g have landed: everything younger (PD-1 steps) may fly
+                // (waves that bring query rows issue 6 vector-memory instructions per step, the others 4)
+#define RING_WAIT(N)                                                                                             \
+    asm volatile("s_waitcnt vmcnt(%4)"                                                                           \
+                 : "+v"(areg[u][0][0]), "+v"(areg[u][0][1]), "+v"(areg[u][1][0]), "+v"(areg[u][1][1])           \
+                 : "n"(N)                                                                                        \
+                 : "memory")
+                if (g + PD > total) RING_WAIT(0);  // tail of the slice: nothing is issued any more
+                else if (wave < NT) RING_WAIT((PD - 1) * 6);
+                else RING_WAIT((PD - 1) * 4);
+#undef RING_WAIT
+                __builtin_amdgcn_s_barrier();  // query slab g visible; every wave is done with slab g-1
+                if (g + PD < total) issue_q(g + PD);  // into the slot of slab g-1
+                const unsigned char* slot = smem + (g % QD) * RQ_SLOT + b_off;
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) {
+                    half8_t b[NT];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const half8_t*>(slot + kh * 8192 + n * 1024);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(areg[u][m][kh], b[n], acc[m][n], 0, 0, 0);
+                }
+                // refill the ring slot with step g + PD (same position of the next block of steps)
+                if (g + PD < total) {
+                    if (refill_next_tile) load_a(areg[u], nbase, s0 + PD - ns + u);
+                    else load_a(areg[u], abase, s0 + PD + u);
+                }
+            }
+        }
+        abase[0] = nbase[0];
+        abase[1] = nbase[1];
+
+        // ---- row tile complete: threshold filter; fold the candidate buffers when due ----
+        const long long left = r_end - row0;
+        if (left >= TM) filter_tile<2, NT, true>(acc, wave * 32, 0, frow, fq, row0, TM, cand, thr_l, cnt_l, flag_l);
+        else filter_tile<2, NT, false>(acc, wave * 32, 0, frow, fq, row0, (int)left, cand, thr_l, cnt_l, flag_l);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's counters and flag are in LDS
+        ++tiles_done;
+        if (((tiles_done & (tiles_done - 1)) == 0 && (tiles_done & 0x55555555u)) || *flag_l) {
+            __syncthreads();  // drains the candidate stores (and the row stream, once per compaction)
+            for (int ql = wave; ql < N128_TN; ql += 8)
+                if (ql < P.nq) compact_query<R>(ql, ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
+            __syncthreads();
+            if (tid == 0) *flag_l = 0;
+            // the loads of the register ring were drained with everything else, which the counted waits
+            // of the next steps tolerate (they only ever wait for MORE than is outstanding)
+        }
+    }
+
+    // ---- end of slice: fold what is left; the k-list is the partial result ----
+    __syncthreads();
+    for (int ql = wave; ql < N128_TN; ql += 8)
+        if (ql < P.nq) compact_query<R>(ql, ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
+}
+
+template <int PD, int NT>
+static hipError_t launch_pd(const MfmaParams& P, int r, int grid, hipStream_t s) {
+    const size_t lds = (size_t)(PD + 1) * RQ_SLOT + 3 * N128_TN * 4 + 16;
+    hipError_t e;
+#define LAUNCH_R(RR)                                                                                    \
+    case RR: {                                                                                          \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(flat_mfma_r128_kernel<RR, PD, NT>),      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+        if (e != hipSuccess) return e;                                                                  \
+        hipLaunchKernelGGL((flat_mfma_r128_kernel<RR, PD, NT>), dim3(grid), dim3(512), lds, s, P);     \
+        break;                                                                                          \
+    }
+    switch (r) {
+        LAUNCH_R(1) LAUNCH_R(2) LAUNCH_R(4)
+        default: return hipErrorInvalidValue;
+    }
+#undef LAUNCH_R
+    return hipGetLastError();
+}
+
+// Ring depth by query blocks: 1 or 4 blocks leave room for a ring of 8 steps (256 KiB of rows in flight per CU);
+// 8 blocks (128 queries: 64 accumulator + 32 fragment registers) for 4.  Every instantiation must compile to
+// `ScratchSize: 0`: a spill of a ring register whose load is still in flight would store garbage.
+bool mfma_r128_supported(int ld, int k) { return (ld % 512) == 0 && k <= 256; }
+hipError_t launch_flat_mfma_r128(const MfmaParams& P, int r, int grid, hipStream_t s) {
+    if (P.nq <= 16) return launch_pd<8, 1>(P, r, grid, s);
+    if (P.nq <= 64) return launch_pd<8, 4>(P, r, grid, s);
+    return launch_pd<4, 8>(P, r, grid, s);
+}
+
+}  // namespace ssmi
