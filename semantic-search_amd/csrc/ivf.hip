@@ -796,6 +796,8 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
     bool list_major = nq >= 16 && nq * (int64_t)nprobe >= 2 * (int64_t)h->nlist;
     if (env_lm) list_major = env_lm[0] == '1';
     list_major = list_major && plan_ivf_list_scan(R.dtype, R.ld, k, &lbt, &lthreads, &llds);
+    const char* env_lmm = getenv("SSMI_IVF_LIST_MFMA");  // 0: keep the register-FMA form
+    const bool list_mfma = list_major && ivf_list_mfma_supported(R.dtype, R.ld, k) && !(env_lmm && env_lmm[0] == '0');
     const size_t per_q = list_major ? (size_t)nprobe * k * sizeof(skey_t) : (size_t)gx * k * sizeof(skey_t);
     const int64_t qbatch = std::max<int64_t>(1, std::min<int64_t>(nq, ((size_t)256 << 20) / per_q));
     for (int64_t done = 0; done < nq; done += qbatch) {
@@ -809,18 +811,29 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
         CHECK(store_search(h, C, nb, qb, nprobe, (float*)h->ws[6], (int64_t*)h->ws[7], 0, s, false));
         if (list_major) {
             CHECK(ensure_ws(h, 2, (size_t)nb * nprobe * k * sizeof(skey_t)));
-            CHECK(ensure_ws(h, 11, (size_t)(4 * h->nlist + 2) * 4));
+            CHECK(ensure_ws(h, 11, (size_t)(4 * h->nlist + 3) * 4));
             CHECK(ensure_ws(h, 12, (size_t)nb * nprobe * 4));
             IvfListScanArgs A;
             A.X = R.view(); A.Q = qb; A.Ic = (const int64_t*)h->ws[7]; A.nq = nb; A.nprobe = nprobe; A.nlist = h->nlist;
             A.k = k; A.page_off = S->d_page_off; A.pages = S->d_pages; A.list_size = S->d_size; A.slot_ids = S->d_slot_ids;
-            A.cnt = (int*)h->ws[11]; A.cursor = A.cnt + h->nlist; A.eoff = A.cursor + h->nlist; A.uoff = A.eoff + h->nlist + 1;
+            A.cnt = (int*)h->ws[11]; A.cursor = A.cnt + h->nlist; A.eoff = A.cursor + h->nlist + 1; A.uoff = A.eoff + h->nlist + 1;
             A.entries = (int*)h->ws[12]; A.partial = (skey_t*)h->ws[2];
-            A.bt = lbt; A.threads = lthreads; A.lds = llds;
-            A.max_units = (int)std::min<int64_t>((int64_t)nb * nprobe, (int64_t)nb * nprobe / lbt + h->nlist);
-            if (done == 0) HIPCHECK(hipEventRecord(ev[0], s));
-            HIPCHECK(launch_ivf_list_scan(A, R.dtype, s));
-            if (done == 0) HIPCHECK(hipEventRecord(ev[1], s));
+            if (list_mfma) {
+                // matrix-core form: up to 128 queries per list pass, queries rounded to fp16
+                A.bt = ivf_list_mfma_bt(nb, nprobe, h->nlist); A.threads = 512; A.lds = 0; A.max_units = 0;
+                CHECK(ensure_ws(h, 4, (size_t)nb * R.ld * 2));
+                CHECK(ensure_ws(h, 5, ivf_list_mfma_cand_bytes(h->num_cu)));
+                HIPCHECK(launch_cvt_queries_f16(qb, nb, nb, R.ld, h->ws[4], s));
+                if (done == 0) HIPCHECK(hipEventRecord(ev[0], s));
+                HIPCHECK(launch_ivf_list_scan_mfma(A, h->ws[4], h->ws[5], h->num_cu, s));
+                if (done == 0) HIPCHECK(hipEventRecord(ev[1], s));
+            } else {
+                A.bt = lbt; A.threads = lthreads; A.lds = llds;
+                A.max_units = (int)std::min<int64_t>((int64_t)nb * nprobe, (int64_t)nb * nprobe / lbt + h->nlist);
+                if (done == 0) HIPCHECK(hipEventRecord(ev[0], s));
+                HIPCHECK(launch_ivf_list_scan(A, R.dtype, s));
+                if (done == 0) HIPCHECK(hipEventRecord(ev[1], s));
+            }
             HIPCHECK(launch_merge_keys((const skey_t*)h->ws[2], nb, nprobe, k, Ddev + (size_t)done * k,
                                        Idev + (size_t)done * k, id_offset, s));
             if (done == 0) HIPCHECK(hipEventRecord(ev[2], s));
@@ -887,7 +900,7 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
     h->n_searches++;
     h->timing_valid = true;
     h->timing.last_path = 2;
-    h->timing.last_grid = list_major ? -lbt : gx;  // negative: list-major scan with that many queries per work item
+    h->timing.last_grid = list_major ? -(list_mfma ? ivf_list_mfma_bt(std::min<int64_t>(nq, qbatch), nprobe, h->nlist) : lbt) : gx;  // negative: list-major scan with that many queries per work item
     h->timing.last_scan_bytes = -1;  // depends on the probed lists; see ssmi_index_get_list_sizes
     h->timing.last_scan_flops = -1;
     return 0;

@@ -15,7 +15,8 @@ struct IvfListScanArgs {
     const uint32_t* slot_ids;
     // workspaces
     int* cnt;                   // nlist probes per list, followed by ...
-    int* cursor;                // ... nlist fill cursors (cursor == cnt + nlist: zeroed together)
+    int* cursor;                // ... nlist fill cursors (cursor == cnt + nlist) and ONE work counter (cnt[2*nlist]),
+                                // all zeroed together
     int* eoff;                  // nlist+1
     int* uoff;                  // nlist+1
     int* entries;               // nq*nprobe (query*nprobe + probe), grouped by list
@@ -26,6 +27,14 @@ struct IvfListScanArgs {
 
 // queries per work item, block size and LDS bytes for this row length and k; false when a query does not fit LDS
 bool plan_ivf_list_scan(int dtype, int ld, int k, int* bt, int* threads, size_t* lds);
+hipError_t launch_ivf_probe_table(const IvfListScanArgs& A, hipStream_t s);
 hipError_t launch_ivf_list_scan(const IvfListScanArgs& A, int dtype, hipStream_t s);
+
+// MFMA form (ivf_lists_mfma.hip): fp16 lists, rows of a multiple of 512 elements, k <= 256
+bool ivf_list_mfma_supported(int dtype, int ld, int k);
+int ivf_list_mfma_bt(long long nq, int nprobe, int nlist);  // queries per work item: 16, 64 or 128
+size_t ivf_list_mfma_cand_bytes(int num_cu);
+// A.bt from ivf_list_mfma_bt; qh: (nq, ld) fp16 queries; cand: ivf_list_mfma_cand_bytes workspace
+hipError_t launch_ivf_list_scan_mfma(const IvfListScanArgs& A, const void* qh, void* cand, int num_cu, hipStream_t s);
 
 }  // namespace ssmi

@@ -232,16 +232,21 @@ static hipError_t launch_t(const IvfListScanArgs& A, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_ivf_list_scan(const IvfListScanArgs& A, int dtype, hipStream_t s) {
+// inverts the probe table: cnt/eoff/uoff/entries (A.cnt, A.cursor and the work counter behind them are zeroed first)
+hipError_t launch_ivf_probe_table(const IvfListScanArgs& A, hipStream_t s) {
     const long long n_entries = (long long)A.nq * A.nprobe;
-    hipError_t e = hipMemsetAsync(A.cnt, 0, sizeof(int) * 2 * (size_t)A.nlist, s);  // cnt and cursor are adjacent
+    hipError_t e = hipMemsetAsync(A.cnt, 0, sizeof(int) * (2 * (size_t)A.nlist + 1), s);  // cnt, cursor, work counter
     if (e != hipSuccess) return e;
     const unsigned eb = (unsigned)((n_entries + 255) / 256);
     hipLaunchKernelGGL(ivf_probe_count_kernel, dim3(eb), dim3(256), 0, s, A.Ic, n_entries, A.cnt);
     hipLaunchKernelGGL(ivf_probe_offsets_kernel, dim3(1), dim3(1024), 0, s, (const int*)A.cnt, A.nlist, A.bt, A.eoff, A.uoff);
     hipLaunchKernelGGL(ivf_probe_fill_kernel, dim3(eb), dim3(256), 0, s, A.Ic, n_entries, (const int*)A.eoff, A.cursor,
                        A.entries, A.partial, A.k);
-    e = hipGetLastError();
+    return hipGetLastError();
+}
+
+hipError_t launch_ivf_list_scan(const IvfListScanArgs& A, int dtype, hipStream_t s) {
+    hipError_t e = launch_ivf_probe_table(A, s);
     if (e != hipSuccess) return e;
     return dtype == 0 ? launch_t<float>(A, s) : launch_t<__half>(A, s);
 }

@@ -33,6 +33,9 @@ bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_c
 hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, const MfmaPlan& p, void* qh, void* cand,
                             skey_t* partial, hipStream_t s);
 
+// (nq, ld) fp32 queries -> (rows_out >= nq, ld) fp16, zero rows beyond nq
+hipError_t launch_cvt_queries_f16(const float* q, int nq, int rows_out, int ld, void* out, hipStream_t s);
+
 // K3: merge P sorted k-lists of keys per query -> (D, I)
 hipError_t launch_merge_keys(const skey_t* partial, int nq, int P, int k, float* D, int64_t* I,
                              int64_t id_offset, hipStream_t s);

@@ -34,6 +34,12 @@ __global__ void cvt_queries_f16_kernel(const float* __restrict__ q, int nq, int 
         out[(size_t)i * ld + e] = (i < nq) ? (_Float16)q[(size_t)i * ld + e] : (_Float16)0.f;
 }
 
+// (nq, ld) fp32 -> (rows_out, ld) fp16, zero rows beyond nq
+hipError_t launch_cvt_queries_f16(const float* q, int nq, int rows_out, int ld, void* out, hipStream_t s) {
+    hipLaunchKernelGGL(cvt_queries_f16_kernel, dim3(rows_out), dim3(256), 0, s, q, nq, ld, (_Float16*)out);
+    return hipGetLastError();
+}
+
 bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_cu, MfmaPlan* p) {
     if (dtype != 1 || (ld % BK) != 0 || nrows < 1 || nq < 1 || k < 1 || k > kMaxK) return false;
     p->nqt = (nq + TN - 1) / TN;

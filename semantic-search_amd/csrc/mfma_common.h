@@ -40,16 +40,16 @@ static constexpr int EPI_LDS_BYTES = 3 * 256 * 4 + 16;
 // One wave per query.  Candidates arrive unsorted: they are sorted in registers (bitonic
 // network, 64 or 256 at a time) and merged with the kept list by one bitonic merge - far cheaper
 // than one sorted insertion per candidate.
+// `kept`: the query's k-list in global memory (k keys), valid once kept_l[ql] is set.
 template <int R>
-__device__ __forceinline__ void compact_query(int ql, int q, const MfmaParams& P, int slice, skey_t* cand_q,
-                                              float* thr_l, unsigned* cnt_l, unsigned* kept_l) {
+__device__ __forceinline__ void compact_list(int ql, skey_t* kept, int k, skey_t* cand_q, float* thr_l, unsigned* cnt_l,
+                                             unsigned* kept_l) {
     const int lane = lane_id();
     const int n = (int)min(cnt_l[ql], (unsigned)CAND_CAP);
     if (n == 0 && kept_l[ql]) return;  // nothing new: list and threshold stand
-    skey_t* kept = P.partial + ((size_t)q * P.nslices + slice) * P.k;
     WaveTopK<R> t;
     t.init();
-    if (kept_l[ql]) t.merge_from(kept, P.k);
+    if (kept_l[ql]) t.merge_from(kept, k);
     if (n <= 64) {
         WaveTopK<1> c;
         c.v[0] = (lane < n) ? cand_q[lane] : 0;
@@ -67,13 +67,19 @@ __device__ __forceinline__ void compact_query(int ql, int q, const MfmaParams& P
             t.merge_regs(c);
         }
     }
-    const skey_t thrk = t.kth(P.k);
-    t.store(kept, P.k);
+    const skey_t thrk = t.kth(k);
+    t.store(kept, k);
     if (lane == 0) {
         kept_l[ql] = 1;
         cnt_l[ql] = 0;
         thr_l[ql] = (thrk == 0) ? SSMI_NEG_MAX : key_score(thrk);
     }
+}
+// Flat kernels: query q of slice `slice` keeps its list at partial[q][slice][k]
+template <int R>
+__device__ __forceinline__ void compact_query(int ql, int q, const MfmaParams& P, int slice, skey_t* cand_q,
+                                              float* thr_l, unsigned* cnt_l, unsigned* kept_l) {
+    compact_list<R>(ql, P.partial + ((size_t)q * P.nslices + slice) * P.k, P.k, cand_q, thr_l, cnt_l, kept_l);
 }
 
 // LDS atomic add / store issued as opaque instructions: after an LDS-DMA (global_load_lds) the
@@ -112,7 +118,9 @@ __device__ __forceinline__ float vmax2(float a, float b) {
 template <int MT, int NT, bool FULL>
 __device__ __forceinline__ void filter_tile(const f32x4_t (&acc)[MT][NT], int row_base, int q_base, int frow, int fq,
                                             long long row0, int rows_valid, skey_t* cand, const float* thr_l,
-                                            unsigned* cnt_l, unsigned* flag_l) {
+                                            unsigned* cnt_l, unsigned* flag_l, const uint32_t* ids = nullptr) {
+    // ids == nullptr: the id of row rr of the tile is row0 + rr (Flat).  Otherwise ids[rr - row_base] (IVF: the
+    // wave's rows are the slots of one list page, whose vector ids are looked up only for survivors).
     // acc[m][n]: rows row_base + m*16 + fq*4 + i of the row tile, query q_base + n*16 + frow of the query tile.
     // keep the per-column LDS/global addresses out of the main loop's register budget: they are
     // recomputed here per row tile instead of being hoisted (and spilled) by the compiler
@@ -155,7 +163,7 @@ __device__ __forceinline__ void filter_tile(const f32x4_t (&acc)[MT][NT], int ro
                 const float s = acc[m][n][i];
                 const int rr = row_base + m * 16 + fq * 4 + i;
                 if (s >= thr && (FULL || rr < rows_valid)) {
-                    if (pos < (unsigned)CAND_CAP) cq[pos] = make_key(s, (uint32_t)(row0 + rr));
+                    if (pos < (unsigned)CAND_CAP) cq[pos] = make_key(s, ids ? ids[rr - row_base] : (uint32_t)(row0 + rr));
                     ++pos;
                 }
             }

@@ -173,11 +173,18 @@ def test_list_sharded_ivf_equals_unsharded(ssa):
         assert torch.equal(I, Iw) and torch.equal(D, Dw), nprobe
 
 
-@pytest.mark.parametrize("n,d,nlist,storage,nq", [(6000, 256, 40, "f32", 37), (3000, 4096, 16, "f32", 20),
-                                                   (5000, 1024, 64, "f16", 130), (2000, 100, 10, "f32", 16)])
-def test_list_major_batched_scan_matches_oracle_and_per_query_scan(ssa, monkeypatch, n, d, nlist, storage, nq):
-    """K8b (ivf_lists.hip): the list-major scan of a query batch must give exactly what the per-query
-    scan gives, and both must match the oracle fed with the index's own list assignment."""
+@pytest.mark.parametrize("n,d,nlist,storage,nq,list_mfma", [
+    (6000, 256, 40, "f32", 37, "0"), (3000, 4096, 16, "f32", 20, "0"), (5000, 1024, 64, "f16", 130, "0"),
+    (2000, 100, 10, "f32", 16, "0"),
+    (5000, 1024, 64, "f16", 130, "1"),    # matrix-core form: 16 queries per list pass (130*nprobe/64 probes per list)
+    (9000, 512, 8, "f16", 200, "1"),      # ... 64 / 128 queries per list pass, lists of > 1000 rows, ragged last pages
+    (3000, 4096, 6, "f16", 33, "1"),
+])
+def test_list_major_batched_scan_matches_oracle_and_per_query_scan(ssa, monkeypatch, n, d, nlist, storage, nq, list_mfma):
+    """K8b (ivf_lists.hip) and K8m (ivf_lists_mfma.hip): the list-major scan of a query batch must give what the
+    per-query scan gives, and both must match the oracle fed with the index's own list assignment.  The
+    register-FMA form is exact in fp32; the matrix-core form rounds the queries to fp16 (north-star tolerance)."""
+    monkeypatch.setenv("SSMI_IVF_LIST_MFMA", list_mfma)
     X = clustered_rows(n, d, nlist, 71)
     C = clustered_rows(nlist, d, nlist, 72)
     index = make_ivf(ssa, d, nlist, storage)
@@ -189,18 +196,29 @@ def test_list_major_batched_scan_matches_oracle_and_per_query_scan(ssa, monkeypa
     for nprobe in (1, 3, nlist):
         index.nprobe = nprobe
         for k in (10, 100, 300):
+            mfma = list_mfma == "1" and k <= 256          # the matrix-core form covers k <= 256
             monkeypatch.setenv("SSMI_IVF_LISTMAJOR", "1")
             D, I = index.search(Q, k)
             assert index.last_timing()["last_grid"] < 0, "list-major path not taken"
+            if mfma:
+                assert -index.last_timing()["last_grid"] in (16, 64, 128)
             monkeypatch.setenv("SSMI_IVF_LISTMAJOR", "0")
             D2, I2 = index.search(Q, k)
             assert index.last_timing()["last_grid"] > 0
-            np.testing.assert_array_equal(I, I2)
-            np.testing.assert_array_equal(D, D2)
             coarse = dict(C_coarse=r16(C), Q_coarse=r16(Q)) if (nq >= 9 and d % 64 == 0) else {}
-            Dr, Ir, _ = ivf_flat.search(Xs, C, labels, Q, k, nprobe, **coarse)
+            if mfma:
+                # fp16 rounding of a unit query moves a score by ~2^-11 * |q||x| / sqrt(d) ~ 1.5e-5 absolute:
+                # the north star's 1e-3 relative bound needs an absolute floor for scores near zero
+                ok, msg, _ = flat_ip.check_against(D, I, D2, I2, Xs, Q, rtol=1e-3, tie_rtol=1e-3, atol=1e-4)
+                assert ok, f"nprobe={nprobe} k={k} vs per-query scan: {msg}"
+                Dr, Ir, _ = ivf_flat.search(Xs, C, labels, r16(Q), k, nprobe, **coarse)
+            else:
+                np.testing.assert_array_equal(I, I2)
+                np.testing.assert_array_equal(D, D2)
+                Dr, Ir, _ = ivf_flat.search(Xs, C, labels, Q, k, nprobe, **coarse)
+            Qs = r16(Q) if mfma else Q
             if nprobe == nlist or not coarse:
-                ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xs, Q, rtol=1e-5, tie_rtol=1e-5)
+                ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xs, Qs, rtol=1e-5, tie_rtol=1e-5)
                 assert ok, f"nprobe={nprobe} k={k}: {msg}"
             else:  # fp16 coarse scores may swap two near-tied centroids at the probe boundary
                 agree = np.mean([len(set(a[a >= 0]) & set(b[b >= 0])) / max(1, (b >= 0).sum()) for a, b in zip(I, Ir)])
