@@ -45,6 +45,7 @@ def parse():
                     help="flat = BASELINE configs[1] (the default bench line); ivf = configs[3] (IVF4096, nprobe 32; 1 GPU)")
     ap.add_argument("--nlist", type=int, default=4096)
     ap.add_argument("--nprobe", type=int, default=32)
+    ap.add_argument("--ivf-sorted", action="store_true", help="IVF workload: clustered rows arrive cluster by cluster (list pages contiguous)")
     ap.add_argument("--ivf-data", default="clustered", choices=["clustered", "iid"],
                     help="clustered: unit rows around 16384 random centres (sigma 0.6); iid: unit gaussian rows")
     return ap.parse_args()
@@ -62,10 +63,13 @@ def run_ivf(args):
     centres = torch.randn((ncl, d), generator=g, device=dev)
     centres /= centres.norm(dim=1, keepdim=True)
 
-    def rows(m):
+    def rows(m, first=None):
         x = torch.randn((m, d), generator=g, device=dev) * (sigma / d ** 0.5 if args.ivf_data == "clustered" else 1.0)
         if args.ivf_data == "clustered":
-            x += centres[torch.randint(0, ncl, (m,), generator=g, device=dev)]
+            if first is None or not args.ivf_sorted:
+                x += centres[torch.randint(0, ncl, (m,), generator=g, device=dev)]
+            else:  # rows arrive cluster by cluster: the pages of a list end up next to each other
+                x += centres[(torch.arange(first, first + m, device=dev) * ncl) // n]
         return x / x.norm(dim=1, keepdim=True)
 
     ivf = ssa.IndexIVFFlat(ssa.IndexFlatIP(d, storage="f16"), d, nlist, ssa.METRIC_INNER_PRODUCT, storage="f16")
@@ -78,7 +82,7 @@ def run_ivf(args):
     del xt
     t_add = 0.0
     for s0 in range(0, n, 65536):
-        x = rows(min(65536, n - s0))
+        x = rows(min(65536, n - s0), s0)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         ivf.add(x)
         t_add += time.perf_counter() - t0
@@ -87,13 +91,16 @@ def run_ivf(args):
     ivf.nprobe = nprobe
     ls = ivf.list_sizes()
     Q = rows(1000)
+    # the timed loop runs as a serving loop would: no hipEvent records between the kernels (each costs the
+    # stream ~6 us); the kernel time for the roofline comes from the 32 timed sample launches below
+    ivf.set_timing(False)
     for i in range(args.warmup):
         ivf.search(Q[i:i + 1], k)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(args.steps):
         ivf.search(Q[i % 1000:i % 1000 + 1], k)
     torch.cuda.synchronize(); elapsed = time.perf_counter() - t0
-    scan_ms = float(np.mean(ivf.scan_times_ms(min(args.steps, 256))))
+    ivf.set_timing(True)
     # algorithmic bytes = rows of the probed lists x d x 2 B, measured per query: the bench
     # reads back the prefix-sum total of each of 32 sample queries together with that launch's hipEvent time
     rows_s, ms_s = [], []
@@ -130,7 +137,7 @@ def run_ivf(args):
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "algorithmic_bytes_note": "mean rows of the probed lists over 32 sample queries (%d; nprobe*N/nlist = %d) x d x 2 B, "
                                                "over the mean hipEvent time of those launches" % (int(probed_rows), int(nprobe * n / nlist)),
-                     "kernel": "ivf_scan_topk_kernel", "kernel_avg_ms": scan_ms_sample, "kernel_avg_ms_timed_steps": scan_ms},
+                     "kernel": "ivf_scan_qreg_kernel", "kernel_avg_ms": scan_ms_sample},
         "extra": {"train_s": t_train, "add_s": t_add, "add_vectors_per_s": n / t_add,
                   "list_sizes": {"min": int(ls.min()), "median": float(np.median(ls)), "max": int(ls.max())},
                   "batch_1000_qps": 1000 / t_b, "batch_4096_qps": 4096 / t_b4, "recall_at_%d_vs_flat" % k: recall,

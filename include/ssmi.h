@@ -151,6 +151,12 @@ int ssmi_index_get_timing(const ssmi_index* h, ssmi_timing* out);
 /* hipEvent durations (ms) of the dominant kernel (scan / contraction) of the last
  * min(max_n, 256) searches on this handle, oldest first (bench.py's roofline leg). */
 int ssmi_index_get_scan_times(const ssmi_index* h, int max_n, float* ms_out, int* n_out);
+/* Switches the per-search hipEvent triple on (default; env SSMI_TIMING=0 starts with it off) or off.
+ * An event record between two kernels costs the stream about 6 us of idle time on this device, three
+ * of them 12 % of a batch-1 IVF search, so a serving loop turns it off; get_timing then reports -1 ms
+ * and get_scan_times only the searches that ran with it on.  No counterpart in the reference (FAISS has
+ * no per-search device timing); measurement plumbing of SURVEY.md 8(d). */
+int ssmi_index_set_timing(ssmi_index* h, int enabled);
 /* IVF introspection for tests: list sizes (nlist int64) */
 int ssmi_index_get_list_sizes(const ssmi_index* h, int64_t* out_host);
 /* ... and the list each stored vector was assigned to (ntotal int32, indexed by id) */

@@ -151,6 +151,11 @@ static int create_common(int d, int storage_dtype, int device, int kind, ssmi_in
     HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (int i = 0; i < ssmi_index::kEvRing; ++i)
         for (int j = 0; j < 3; ++j) HIPCHECK(hipEventCreate(&h->ev[i][j]));
+    if (!getenv("SSMI_NO_TAIL")) {
+        HIPCHECK(hipMalloc((void**)&h->tail_counters, ssmi_index::kTailCounters * sizeof(unsigned)));
+        HIPCHECK(hipMemset(h->tail_counters, 0, ssmi_index::kTailCounters * sizeof(unsigned)));
+    }
+    if (const char* e = getenv("SSMI_TIMING")) h->timing_on = e[0] != '0';
     if (h->rows.init(d, storage_dtype)) { delete h; return 1; }
     *out = h;
     return 0;
@@ -204,6 +209,7 @@ int ssmi_index_free(ssmi_index* h) {
     h->rows.destroy();
     if (h->has_shadow) h->shadow16.destroy();
     for (int i = 0; i < kWsSlots; ++i) if (h->ws[i]) (void)hipFree(h->ws[i]);
+    if (h->tail_counters) (void)hipFree(h->tail_counters);
     for (int i = 0; i < ssmi_index::kEvRing; ++i)
         for (int j = 0; j < 3; ++j) if (h->ev[i][j]) (void)hipEventDestroy(h->ev[i][j]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -347,15 +353,16 @@ static int store_search_mfma(ssmi_index* h, const RowStore& R, int64_t nq, const
         CHECK(ensure_ws(h, 5, p.cand_bytes));
         CHECK(ensure_ws(h, 2, (size_t)nb * p.nslices * k * sizeof(skey_t)));
         skey_t* partial = (skey_t*)h->ws[2];
-        if (record && done == 0) HIPCHECK(hipEventRecord(ev[0], s));
+        if (record && h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[0], s));
         HIPCHECK(launch_flat_mfma(R.view(), qdev + (size_t)done * R.ld, nb, k, p, h->ws[4], h->ws[5], partial, s));
-        if (record && done == 0) HIPCHECK(hipEventRecord(ev[1], s));
+        if (record && h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[1], s));
         HIPCHECK(launch_merge_keys(partial, nb, p.nslices, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
                                    id_offset, s));
-        if (record && done == 0) HIPCHECK(hipEventRecord(ev[2], s));
+        if (record && h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[2], s));
     }
     if (!record) return 0;
-    h->n_searches++;
+    if (h->timing_on) h->n_searches++;
+    h->events_valid = h->timing_on;
     h->timing_valid = true;
     h->timing.last_path = 1;
     h->timing.last_grid = p.grid;
@@ -402,18 +409,24 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
         CHECK(ensure_ws(h, 2, (size_t)nb * per_q));
         skey_t* partial = (skey_t*)h->ws[2];
         const float* qb = qdev + (size_t)done * R.ld;
-        if (record && first) HIPCHECK(hipEventRecord(ev[0], s));
+        // the scan merges its own per-block lists when a ticket counter per query tile is at hand
+        const bool tail = h->tail_counters && p.grid_y <= ssmi_index::kTailCounters;
+        p.tail = TailMerge{tail ? h->tail_counters : nullptr, Ddev + (size_t)done * k, Idev + (size_t)done * k, id_offset};
+        const bool rec = record && first && h->timing_on;
+        if (rec) HIPCHECK(hipEventRecord(ev[0], s));
         if (R.dtype == SSMI_F32) HIPCHECK(launch_flat_scan_f32(R.view(), qb, (int)nb, k, partial, p, s));
         else HIPCHECK(launch_flat_scan_f16(R.view(), qb, (int)nb, k, partial, p, s));
-        if (record && first) HIPCHECK(hipEventRecord(ev[1], s));
-        HIPCHECK(launch_merge_keys(partial, (int)nb, p.grid_x, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
-                                   id_offset, s));
-        if (record && first) HIPCHECK(hipEventRecord(ev[2], s));
+        if (rec) HIPCHECK(hipEventRecord(ev[1], s));
+        if (!tail)
+            HIPCHECK(launch_merge_keys(partial, (int)nb, p.grid_x, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
+                                       id_offset, s));
+        if (rec) HIPCHECK(hipEventRecord(ev[2], s));
         first = false;
         done += nb;
     }
     if (!record) return 0;
-    h->n_searches++;
+    if (h->timing_on) h->n_searches++;
+    h->events_valid = h->timing_on;
     h->timing_valid = true;
     h->timing.last_path = 0;
     h->timing.last_grid = p.grid_x * p.grid_y;
@@ -523,14 +536,16 @@ int ssmi_index_get_timing(const ssmi_index* h, ssmi_timing* out) {
     if (!h->timing_valid) return fail("no search has run on this index");
     DeviceGuard g(h->device);
     ssmi_timing t = h->timing;
-    hipEvent_t const* ev = h->ev[(h->n_searches - 1) % ssmi_index::kEvRing];
-    HIPCHECK(hipEventSynchronize(ev[2]));
-    float a = 0, b = 0;
-    HIPCHECK(hipEventElapsedTime(&a, ev[0], ev[1]));
-    HIPCHECK(hipEventElapsedTime(&b, ev[1], ev[2]));
+    float a = -1.f, b = -1.f;  // -1: the last search ran with timing switched off
+    if (h->events_valid) {
+        hipEvent_t const* ev = h->ev[(h->n_searches - 1) % ssmi_index::kEvRing];
+        HIPCHECK(hipEventSynchronize(ev[2]));
+        HIPCHECK(hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIPCHECK(hipEventElapsedTime(&b, ev[1], ev[2]));
+    }
     t.last_scan_ms = a;
     t.last_merge_ms = b;
-    t.last_search_ms = a + b;
+    t.last_search_ms = h->events_valid ? a + b : -1.f;
     if (t.last_path == 2 && t.last_grid > 0 && h->ws[10]) {
         // per-query IVF scan: rows probed by the first query of the last search (its prefix-sum total)
         long long rows = 0;
@@ -540,6 +555,12 @@ int ssmi_index_get_timing(const ssmi_index* h, ssmi_timing* out) {
         t.last_scan_flops = 2 * rows * (int64_t)h->rows.d;
     }
     *out = t;
+    return 0;
+}
+
+int ssmi_index_set_timing(ssmi_index* h, int enabled) {
+    if (!h) return fail("NULL index");
+    h->timing_on = enabled != 0;
     return 0;
 }
 

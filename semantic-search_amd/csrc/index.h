@@ -44,11 +44,16 @@ struct ssmi_index {
     // ring of (scan start, scan stop, merge stop) event triples, one per search call
     static const int kEvRing = 256;
     hipEvent_t ev[kEvRing][3] = {};
-    long long n_searches = 0;
+    long long n_searches = 0;  // searches that recorded an event triple
     void* ws[ssmi::kWsSlots] = {};
     size_t ws_bytes[ssmi::kWsSlots] = {};
     ssmi_timing timing = {};
     bool timing_valid = false;
+    bool timing_on = true;  // record the event triple of every search (ssmi_index_set_timing)
+    bool events_valid = false;  // the last search recorded its events
+    // ticket counters of the merge tails (tail_merge.h): zero between launches, one per query (tile)
+    static const int kTailCounters = 4096;
+    unsigned* tail_counters = nullptr;
 
     // ---- IVF state (kind == SSMI_KIND_IVFFLAT) ----
     int nlist = 0, nprobe = 1;

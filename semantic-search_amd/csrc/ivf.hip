@@ -174,6 +174,7 @@ struct IvfScanParams {
     const uint32_t* slot_ids;
     int nprobe, k;
     skey_t* partial;            // [nq][gridDim.x][k]
+    TailMerge tail;             // counter set: the last block of a query merges its lists into (D, I)
 };
 
 // K8: bucketed list scan with fused per-wavefront top-k.  grid = (gx, nq), 4 waves.
@@ -266,7 +267,11 @@ __global__ void __launch_bounds__(256) ivf_scan_topk_kernel(IvfScanParams P) {
     __syncthreads();
     skey_t* lds_keys = reinterpret_cast<skey_t*>(smem);
     block_merge<R>(top, lds_keys, wave, 4);
-    if (wave == 0) top.store(P.partial + ((size_t)q * gridDim.x + blockIdx.x) * P.k, P.k);
+    if (wave == 0) publish_list<R>(top, P.partial + ((size_t)q * gridDim.x + blockIdx.x) * P.k, P.k);
+    if (P.tail.counter == nullptr) return;
+    if (!tail_last_block(P.tail.counter + q, gridDim.x, reinterpret_cast<unsigned*>(lds_keys))) return;
+    merge_partials<R, true>(P.partial + (size_t)q * gridDim.x * P.k, (int)gridDim.x, P.k, lds_keys, wave, 4,
+                      P.tail.D + (size_t)q * P.k, P.tail.I + (size_t)q * P.k, P.tail.id_offset);
 }
 
 // K8, register-query form for rows of NCH KiB (d = 4096: NCH 8 for fp16, 16 for fp32; also 2048, 1024):
@@ -404,7 +409,11 @@ __global__ void __launch_bounds__(R <= 4 ? 768 : 512) ivf_scan_qreg_kernel(IvfSc
     }
     skey_t* lds_keys = reinterpret_cast<skey_t*>(smem);
     block_merge<R>(top, lds_keys, wave, nwaves);
-    if (wave == 0) top.store(P.partial + ((size_t)q * gridDim.x + blockIdx.x) * P.k, P.k);
+    if (wave == 0) publish_list<R>(top, P.partial + ((size_t)q * gridDim.x + blockIdx.x) * P.k, P.k);
+    if (P.tail.counter == nullptr) return;
+    if (!tail_last_block(P.tail.counter + q, gridDim.x, reinterpret_cast<unsigned*>(lds_keys))) return;
+    merge_partials<R, true>(P.partial + (size_t)q * gridDim.x * P.k, (int)gridDim.x, P.k, lds_keys, wave, nwaves,
+                      P.tail.D + (size_t)q * P.k, P.tail.I + (size_t)q * P.k, P.tail.id_offset);
 }
 
 // ---------------------------------------------------------------------------
@@ -824,19 +833,19 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
                 CHECK(ensure_ws(h, 4, (size_t)nb * R.ld * 2));
                 CHECK(ensure_ws(h, 5, ivf_list_mfma_cand_bytes(h->num_cu)));
                 HIPCHECK(launch_cvt_queries_f16(qb, nb, nb, R.ld, h->ws[4], s));
-                if (done == 0) HIPCHECK(hipEventRecord(ev[0], s));
+                if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[0], s));
                 HIPCHECK(launch_ivf_list_scan_mfma(A, h->ws[4], h->ws[5], h->num_cu, s));
-                if (done == 0) HIPCHECK(hipEventRecord(ev[1], s));
+                if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[1], s));
             } else {
                 A.bt = lbt; A.threads = lthreads; A.lds = llds;
                 A.max_units = (int)std::min<int64_t>((int64_t)nb * nprobe, (int64_t)nb * nprobe / lbt + h->nlist);
-                if (done == 0) HIPCHECK(hipEventRecord(ev[0], s));
+                if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[0], s));
                 HIPCHECK(launch_ivf_list_scan(A, R.dtype, s));
-                if (done == 0) HIPCHECK(hipEventRecord(ev[1], s));
+                if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[1], s));
             }
             HIPCHECK(launch_merge_keys((const skey_t*)h->ws[2], nb, nprobe, k, Ddev + (size_t)done * k,
                                        Idev + (size_t)done * k, id_offset, s));
-            if (done == 0) HIPCHECK(hipEventRecord(ev[2], s));
+            if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[2], s));
             continue;
         }
         hipLaunchKernelGGL(ivf_plan_kernel, dim3(nb), dim3(256), 0, s, (const int64_t*)h->ws[7], nprobe, S->d_size,
@@ -847,7 +856,9 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
         P.X = R.view(); P.Q = qb; P.Ic = (const int64_t*)h->ws[7]; P.prefix = (const long long*)h->ws[10];
         P.page_off = S->d_page_off; P.pages = S->d_pages; P.slot_ids = S->d_slot_ids; P.nprobe = nprobe; P.k = k;
         P.partial = (skey_t*)h->ws[2];
-        if (done == 0) HIPCHECK(hipEventRecord(ev[0], s));
+        const bool tail = h->tail_counters && nb <= ssmi_index::kTailCounters;
+        P.tail = TailMerge{tail ? h->tail_counters : nullptr, Ddev + (size_t)done * k, Idev + (size_t)done * k, id_offset};
+        if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[0], s));
 #define IVF_LAUNCH(TT, RR)                                                                                       \
     case RR: {                                                                                                   \
         if (lds > 48 * 1024)                                                                                     \
@@ -892,12 +903,14 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
 #undef IVF_QLAUNCH
 #undef IVF_QLAUNCH_R
         HIPCHECK(hipGetLastError());
-        if (done == 0) HIPCHECK(hipEventRecord(ev[1], s));
-        HIPCHECK(launch_merge_keys((const skey_t*)h->ws[2], nb, gx, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
-                                   id_offset, s));
-        if (done == 0) HIPCHECK(hipEventRecord(ev[2], s));
+        if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[1], s));
+        if (!tail)
+            HIPCHECK(launch_merge_keys((const skey_t*)h->ws[2], nb, gx, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
+                                       id_offset, s));
+        if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[2], s));
     }
-    h->n_searches++;
+    if (h->timing_on) h->n_searches++;
+    h->events_valid = h->timing_on;
     h->timing_valid = true;
     h->timing.last_path = 2;
     h->timing.last_grid = list_major ? -(list_mfma ? ivf_list_mfma_bt(std::min<int64_t>(nq, qbatch), nprobe, h->nlist) : lbt) : gx;  // negative: list-major scan with that many queries per work item

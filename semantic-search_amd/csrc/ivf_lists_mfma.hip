@@ -100,18 +100,18 @@ __global__ void __launch_bounds__(512) ivf_scan_lists_mfma_kernel(IvfListScanArg
         __syncthreads();
 
         if (total > 0) {
-            // query rows of the group: wave w gathers rows 16w .. 16w+15 (short groups repeat their last query)
-            const int qrow = wave * 16 + (lane >> 2);
+            // query rows of the group, gathered by all 8 waves in equal shares (QSlabDma; short groups repeat
+            // their last query): every wave issues 4 row loads + QOPS DMAs per step, so one counted wait serves
+            // all of them.  Steps past the end of the list repeat the last one (into ring positions nobody
+            // reads any more).
+            using QD_t = QSlabDma<NT>;
+            constexpr int VOPS = 4 + QD_t::OPS;
+            const int qrow = QD_t::qrow(wave, lane);
             const int qe = A.entries[e0 + (qrow < ne ? qrow : ne - 1)] / A.nprobe;
-            const unsigned char* qsrc = reinterpret_cast<const unsigned char*>(Qh) + (size_t)qe * row_bytes +
-                                        ((lane & 3) ^ ((-(qrow >> 2)) & 3)) * 16;
+            const unsigned char* qsrc = reinterpret_cast<const unsigned char*>(Qh) + (size_t)qe * row_bytes + QD_t::src_off(wave, lane);
             auto issue_q = [&](int g) {
-                const int s = g % ns;
-                unsigned char* dst = smem + (g % QD) * LQ_SLOT + wave * 1024;
-                if (wave < NT) {
-                    GLDS16(qsrc + (size_t)s * 128, dst);
-                    GLDS16(qsrc + (size_t)s * 128 + 64, dst + 8192);
-                }
+                const int s = (g < total ? g : total - 1) % ns;
+                QD_t::issue(qsrc + (size_t)s * 128, smem + (g % QD) * LQ_SLOT + QD_t::dst_off(wave));
             };
             // this wave's page of tile t: row base of the lane's two 16-row blocks, first slot, valid rows
             auto tile_page = [&](int t, const unsigned char* (&base)[2], long long& slot0, int& rv) {
@@ -125,6 +125,11 @@ __global__ void __launch_bounds__(512) ivf_scan_lists_mfma_kernel(IvfListScanArg
                     base[m] = segbase + (size_t)((slot0 & seg_mask) + m * 16 + frow) * row_bytes + fq * 16;
             };
             half8_t areg[PD][2][2];
+            // The ring registers are written by the memory system long after the load instruction: between a
+            // load and its counted wait the compiler must neither copy nor reuse them.  Each ring slot is
+            // therefore defined by exactly ONE load statement and ONE wait statement per step (no alternative
+            // definitions that would meet in a phi and be copied), and the ring is drained with the registers
+            // still named before anything else may take them.
             auto load_a = [&](half8_t (&dst)[2][2], const unsigned char* const (&base)[2], int s) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
@@ -166,12 +171,9 @@ __global__ void __launch_bounds__(512) ivf_scan_lists_mfma_kernel(IvfListScanArg
                  : "+v"(areg[u][0][0]), "+v"(areg[u][0][1]), "+v"(areg[u][1][0]), "+v"(areg[u][1][1])           \
                  : "n"(N)                                                                                        \
                  : "memory")
-                        if (g + PD > total) RING_WAIT(0);
-                        else if (wave < NT) RING_WAIT((PD - 1) * 6);
-                        else RING_WAIT((PD - 1) * 4);
-#undef RING_WAIT
+                        RING_WAIT((PD - 1) * VOPS);  // step g landed; the PD-1 younger steps may fly
                         __builtin_amdgcn_s_barrier();
-                        if (g + PD < total) issue_q(g + PD);
+                        issue_q(g + PD);
                         const unsigned char* slot = smem + (g % QD) * LQ_SLOT + b_off;
 #pragma unroll
                         for (int kh = 0; kh < 2; ++kh) {
@@ -185,9 +187,14 @@ __global__ void __launch_bounds__(512) ivf_scan_lists_mfma_kernel(IvfListScanArg
                                 for (int n = 0; n < NT; ++n)
                                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(areg[u][m][kh], b[n], acc[m][n], 0, 0, 0);
                         }
-                        if (g + PD < total) {
-                            if (refill_next_tile) load_a(areg[u], nbase, s0 + PD - ns + u);
-                            else load_a(areg[u], abase, s0 + PD + u);
+                        {   // refill ring slot u with step g + PD (next tile's page when this one is used up; past the
+                            // end of the list: this step again, never consumed)
+                            const bool past = g + PD >= total;
+                            const unsigned char* rb[2];
+                            rb[0] = (refill_next_tile && !past) ? nbase[0] : abase[0];
+                            rb[1] = (refill_next_tile && !past) ? nbase[1] : abase[1];
+                            const int rs = past ? s0 + u : (refill_next_tile ? s0 + PD - ns + u : s0 + PD + u);
+                            load_a(areg[u], rb, rs);
                         }
                     }
                 }
@@ -213,6 +220,10 @@ __global__ void __launch_bounds__(512) ivf_scan_lists_mfma_kernel(IvfListScanArg
                     if (tid == 0) *flag_l = 0;
                 }
             }
+            // drain the ring (the repeated steps of the tail) while its registers are still reserved
+#pragma unroll
+            for (int u = 0; u < PD; ++u) RING_WAIT(0);
+#undef RING_WAIT
         }
         // ---- end of the work item: every (query, probe) pair of the group gets its k-list ----
         __syncthreads();
@@ -226,6 +237,10 @@ bool ivf_list_mfma_supported(int dtype, int ld, int k) { return dtype == 1 && (l
 
 // queries per work item for this batch: the smallest of 16 / 64 / 128 that covers twice the average probes per list
 int ivf_list_mfma_bt(long long nq, int nprobe, int nlist) {
+    if (const char* e = getenv("SSMI_IVF_LIST_BT")) {  // experiments: force the group size
+        const int v = atoi(e);
+        if (v == 16 || v == 64 || v == 128) return v;
+    }
     const double avg = (double)nq * nprobe / nlist;
     return avg <= 8 ? 16 : (avg <= 32 ? 64 : 128);
 }

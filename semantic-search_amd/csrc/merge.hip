@@ -8,55 +8,19 @@
 // the result merge the north-star asks for after the RCCL all-gather.
 #include "kernels.h"
 #include "topk.h"
+#include "tail_merge.h"
 #include <type_traits>
 
 namespace ssmi {
 
 template <int R>
-__device__ __forceinline__ void write_result(const WaveTopK<R>& t, int k, float* D, int64_t* I, int64_t id_offset) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int e = r * 64 + lane;
-        if (e < k) {
-            const skey_t key = t.v[r];
-            if (key == 0) { D[e] = SSMI_NEG_MAX; I[e] = -1; }
-            else { D[e] = key_score(key); I[e] = (int64_t)key_id(key) + id_offset; }
-        }
-    }
-}
-
-template <int R>
 __global__ void merge_keys_kernel(const skey_t* __restrict__ partial, int P, int k, float* __restrict__ D,
                                   int64_t* __restrict__ I, int64_t id_offset) {
     extern __shared__ __align__(16) unsigned char smem[];
-    skey_t* lds = reinterpret_cast<skey_t*>(smem);
     const int q = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nwaves = (int)(blockDim.x >> 6);
-    WaveTopK<R> t;
-    t.init();
-    if (R == 1) {
-        // short lists: treat the P*k keys as one unsorted pool, 256 per wave-step, all loads of a
-        // step in flight together (a chain of P dependent little merges is latency-bound)
-        const skey_t* pool = partial + (size_t)q * P * k;
-        const int total = P * k;
-        const int lane = lane_id();
-        for (int base = wave * 256; base < total; base += nwaves * 256) {
-            WaveTopK<4> c;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int e = base + r * 64 + lane;
-                c.v[r] = (e < total) ? pool[e] : 0;
-            }
-            c.sort_desc();
-            t.merge_regs(c);
-        }
-    } else {
-        for (int p = wave; p < P; p += nwaves) t.merge_from(partial + ((size_t)q * P + p) * k, k);
-    }
-    block_merge<R>(t, lds, wave, nwaves);
-    if (wave == 0) write_result<R>(t, k, D + (size_t)q * k, I + (size_t)q * k, id_offset);
+    merge_partials<R, false>(partial + (size_t)q * P * k, P, k, reinterpret_cast<skey_t*>(smem), wave, (int)(blockDim.x >> 6),
+                      D + (size_t)q * k, I + (size_t)q * k, id_offset);
 }
 
 // lists given as (D, I) pairs laid out [nlists][nq][k]

@@ -33,6 +33,42 @@ struct MfmaParams {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),      \
                                      (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
 
+#define GLDS4(gptr, ldsptr)                                                                       \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),      \
+                                     (__attribute__((address_space(3))) void*)(ldsptr), 4, 0, 0)
+
+// Query-slab DMA of the register-ring kernels (mfma_r128.hip, ivf_lists_mfma.hip).  The slab of one
+// 64-deep K step is [k-half][16*NT queries][64 B] (k-half stride 8 KiB, 16-B chunks XOR-swizzled by
+// row); its 2*NT KiB are split EVENLY over the 8 waves, so that every wave issues the same number of
+// vector-memory instructions per step and one counted s_waitcnt serves all of them:
+//   NT = 8: wave w brings queries 16w..16w+15 of both k-halves      (2 x 16 B per lane)
+//   NT = 4: wave w brings queries 16(w&3).. of k-half w>>2          (1 x 16 B per lane)
+//   NT = 1: wave w brings queries 4(w&3)..4(w&3)+3 of k-half w>>2   (1 x  4 B per lane)
+template <int NT>
+struct QSlabDma {
+    static constexpr int OPS = NT == 8 ? 2 : 1;  // DMA instructions per wave and step
+    // query row (within the tile) whose bytes this lane moves
+    __device__ __forceinline__ static int qrow(int wave, int lane) {
+        return NT == 8 ? wave * 16 + (lane >> 2) : (NT == 4 ? (wave & 3) * 16 + (lane >> 2) : (wave & 3) * 4 + (lane >> 4));
+    }
+    // byte offset of the lane's source inside its query row, for K step 0 (a step advances 128 B)
+    __device__ __forceinline__ static int src_off(int wave, int lane) {
+        const int f = (-(qrow(wave, lane) >> 2)) & 3;
+        if (NT == 8) return ((lane & 3) ^ f) * 16;
+        if (NT == 4) return (wave >> 2) * 64 + ((lane & 3) ^ f) * 16;
+        return (wave >> 2) * 64 + ((((lane & 15) >> 2) ^ f) * 16) + (lane & 3) * 4;
+    }
+    // byte offset of the wave's piece inside a slab slot
+    __device__ __forceinline__ static int dst_off(int wave) {
+        return NT == 8 ? wave * 1024 : (NT == 4 ? (wave >> 2) * 8192 + (wave & 3) * 1024 : (wave >> 2) * 8192 + (wave & 3) * 256);
+    }
+    __device__ __forceinline__ static void issue(const unsigned char* src /*row + src_off + step*128*/, unsigned char* dst) {
+        if (NT == 8) { GLDS16(src, dst); GLDS16(src + 64, dst + 8192); }
+        else if (NT == 4) GLDS16(src, dst);
+        else GLDS4(src, dst);
+    }
+};
+
 // LDS words behind the four operand slabs: thr[256] (float), cnt[256], kept[256], flag
 static constexpr int EPI_LDS_BYTES = 3 * 256 * 4 + 16;
 

@@ -64,17 +64,16 @@ __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
     const int fch = (fq ^ ((-(frow >> 2)) & 3)) * 16;
     const int b_off = frow * 64 + fch;  // + kh * 8192 + n * 1024
 
-    // query slab DMA: wave w brings queries 16w .. 16w+15 of both k-halves (2 pieces of 1 KiB per step)
-    const int qrow = wave * 16 + (lane >> 2);
-    const unsigned char* qsrc = reinterpret_cast<const unsigned char*>(P.Qh) + (size_t)qrow * ld * 2 +
-                                ((lane & 3) ^ ((-(qrow >> 2)) & 3)) * 16;
+    // query slab DMA, shared evenly by the 8 waves (QSlabDma): every wave issues 4 row loads + QOPS DMAs per
+    // step, so one counted wait serves all of them.  Steps past the end of the slice repeat the last one (into
+    // ring positions nobody reads any more).
+    using QD_t = QSlabDma<NT>;
+    constexpr int VOPS = 4 + QD_t::OPS;  // vector-memory instructions per wave and step
+    const unsigned char* qsrc = reinterpret_cast<const unsigned char*>(P.Qh) + (size_t)QD_t::qrow(wave, lane) * ld * 2 +
+                                QD_t::src_off(wave, lane);
     auto issue_q = [&](int g /*global step*/) {
-        const int s = g % ns;
-        unsigned char* dst = smem + (g % QD) * RQ_SLOT + wave * 1024;
-        if (wave < NT) {  // queries 16w .. 16w+15 are scored at all
-            GLDS16(qsrc + (size_t)s * 128, dst);
-            GLDS16(qsrc + (size_t)s * 128 + 64, dst + 8192);
-        }
+        const int s = (g < total ? g : total - 1) % ns;
+        QD_t::issue(qsrc + (size_t)s * 128, smem + (g % QD) * RQ_SLOT + QD_t::dst_off(wave));
     };
     // row base of this lane's two 16-row blocks in row tile `t` (padding rows repeat the last valid row)
     auto tile_rows = [&](int t, const unsigned char* (&base)[2]) {
@@ -95,6 +94,11 @@ __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
     // across this loop nest and would put s_waitcnt vmcnt(0) in front of every use, which turns the register
     // ring into a blocking load.  Completion is enforced by the counted waits below, which take the ring
     // slot's registers as in/out operands so that no use can be scheduled above them.
+    // The ring registers are written by the memory system long after the load instruction: between a load
+    // and its counted wait the compiler must neither copy nor reuse them.  Each ring slot is therefore defined
+    // by exactly ONE load statement and ONE wait statement per step (alternative definitions would meet in a
+    // phi and be copied while in flight), and the ring is drained with the registers still named before the
+    // kernel's tail may take them.  tools/check_ring_regs.py verifies this on the generated assembly.
     auto load_a = [&](half8_t (&dst)[2][2], const unsigned char* const (&base)[2], int s) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -129,19 +133,15 @@ __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
             const bool refill_next_tile = (s0 + PD >= ns);
 #pragma unroll
             for (int u = 0; u < PD; ++u, ++g) {
-                // this wave's loads and DMA of step g have landed: everything younger (PD-1 steps) may fly
-                // (waves that bring query rows issue 6 vector-memory instructions per step, the others 4)
+                // this wave's loads and DMA of step g have landed: everything younger (PD-1 steps of VOPS) may fly
 #define RING_WAIT(N)                                                                                             \
     asm volatile("s_waitcnt vmcnt(%4)"                                                                           \
                  : "+v"(areg[u][0][0]), "+v"(areg[u][0][1]), "+v"(areg[u][1][0]), "+v"(areg[u][1][1])           \
                  : "n"(N)                                                                                        \
                  : "memory")
-                if (g + PD > total) RING_WAIT(0);  // tail of the slice: nothing is issued any more
-                else if (wave < NT) RING_WAIT((PD - 1) * 6);
-                else RING_WAIT((PD - 1) * 4);
-#undef RING_WAIT
+                RING_WAIT((PD - 1) * VOPS);
                 __builtin_amdgcn_s_barrier();  // query slab g visible; every wave is done with slab g-1
-                if (g + PD < total) issue_q(g + PD);  // into the slot of slab g-1
+                issue_q(g + PD);               // into the slot of slab g-1
                 const unsigned char* slot = smem + (g % QD) * RQ_SLOT + b_off;
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh) {
@@ -155,10 +155,14 @@ __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
                         for (int n = 0; n < NT; ++n)
                             acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(areg[u][m][kh], b[n], acc[m][n], 0, 0, 0);
                 }
-                // refill the ring slot with step g + PD (same position of the next block of steps)
-                if (g + PD < total) {
-                    if (refill_next_tile) load_a(areg[u], nbase, s0 + PD - ns + u);
-                    else load_a(areg[u], abase, s0 + PD + u);
+                {   // refill the ring slot with step g + PD (the next row tile's rows when this one is used up;
+                    // past the end of the slice: this step again, never consumed)
+                    const bool past = g + PD >= total;
+                    const unsigned char* rb[2];
+                    rb[0] = (refill_next_tile && !past) ? nbase[0] : abase[0];
+                    rb[1] = (refill_next_tile && !past) ? nbase[1] : abase[1];
+                    const int rs = past ? s0 + u : (refill_next_tile ? s0 + PD - ns + u : s0 + PD + u);
+                    load_a(areg[u], rb, rs);
                 }
             }
         }
@@ -186,6 +190,11 @@ __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
             // of the next steps tolerate (they only ever wait for MORE than is outstanding)
         }
     }
+
+    // drain the ring (the repeated steps of the tail) while its registers are still reserved
+#pragma unroll
+    for (int u = 0; u < PD; ++u) RING_WAIT(0);
+#undef RING_WAIT
 
     // ---- end of slice: fold what is left; the k-list is the partial result ----
     __syncthreads();

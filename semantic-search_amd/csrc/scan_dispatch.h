@@ -14,7 +14,7 @@ static hipError_t launch_one(const RowView& X, const float* Q, int nq, int k, sk
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(p.grid_x, p.grid_y), dim3(p.threads), p.lds, s, X, Q, nq, k, partial);
+    hipLaunchKernelGGL(kern, dim3(p.grid_x, p.grid_y), dim3(p.threads), p.lds, s, X, Q, nq, k, partial, p.tail);
     return hipGetLastError();
 }
 

@@ -19,6 +19,7 @@
 #pragma once
 #include "common.h"
 #include "topk.h"
+#include "tail_merge.h"
 
 namespace ssmi {
 
@@ -68,7 +69,7 @@ __device__ __forceinline__ int q_lds_index(int elem) {
 // registers (BT == 1, NCH > 0 only).
 template <typename T, int NCH, int BT, int R, bool QREG, bool NT>
 __global__ void __launch_bounds__(QREG ? (R <= 4 ? 768 : 512) : 1024) flat_scan_topk_kernel(RowView X, const float* __restrict__ Q, int nq, int k,
-                                      skey_t* __restrict__ partial) {
+                                      skey_t* partial, TailMerge tail) {
     constexpr int V = ElemTraits<T>::V;
     static_assert(!QREG || (BT == 1 && NCH > 0), "QREG needs one query and a static row length");
     extern __shared__ __align__(16) unsigned char smem[];
@@ -189,7 +190,18 @@ __global__ void __launch_bounds__(QREG ? (R <= 4 ? 768 : 512) : 1024) flat_scan_
     for (int b = 0; b < BT; ++b) {
         block_merge<R>(top[b], lds_keys, wave, nwaves);
         if (wave == 0 && (q0 + b) < nq)
-            top[b].store(partial + ((size_t)(q0 + b) * gridDim.x + blockIdx.x) * k, k);
+            publish_list<R>(top[b], partial + ((size_t)(q0 + b) * gridDim.x + blockIdx.x) * k, k);
+        __syncthreads();
+    }
+    if (tail.counter == nullptr) return;
+    // the block that publishes the last list of this query tile merges them all (tail_merge.h)
+    if (!tail_last_block(tail.counter + blockIdx.y, gridDim.x, reinterpret_cast<unsigned*>(smem))) return;
+#pragma unroll 1
+    for (int b = 0; b < BT; ++b) {
+        const int q = q0 + b;
+        if (q >= nq) break;
+        merge_partials<R, true>(partial + (size_t)q * gridDim.x * k, (int)gridDim.x, k, lds_keys, wave, nwaves,
+                          tail.D + (size_t)q * k, tail.I + (size_t)q * k, tail.id_offset);
         __syncthreads();
     }
 }

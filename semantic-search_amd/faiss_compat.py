@@ -217,6 +217,10 @@ class _IndexBase:
         return {name: getattr(t, name) for name, _ in _lib.Timing._fields_}
 
 
+    def set_timing(self, enabled: bool) -> None:
+        """Per-search hipEvent records on (default) or off: each costs the stream ~6 us, so serving loops switch them off."""
+        _lib.check(self._lib.ssmi_index_set_timing(self._handle(), 1 if enabled else 0))
+
     def scan_times_ms(self, max_n: int = 256) -> np.ndarray:
         """hipEvent durations of the dominant kernel of the last searches (oldest first)."""
         out = np.zeros((max_n,), dtype=np.float32)

@@ -14,6 +14,8 @@ ivf.train(rows(min(n, 64 * nlist)))
 for s in range(0, n, 65536):
     ivf.add(rows(min(65536, n - s)))
 ivf.nprobe = nprobe
+if os.environ.get("PROF_TIMING", "1") == "0":
+    ivf.set_timing(False)
 Q = rows(64)
 for i in range(40):
     D, I = ivf.search(Q[i:i + 1], 10)
