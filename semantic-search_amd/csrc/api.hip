@@ -358,7 +358,7 @@ static int store_search_mfma(ssmi_index* h, const RowStore& R, int64_t nq, const
         if (record && h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[1], s));
         HIPCHECK(launch_merge_keys(partial, nb, p.nslices, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
                                    id_offset, s));
-        if (record && h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[2], s));
+        if (record && h->timing_on && done == 0) { HIPCHECK(hipEventRecord(ev[2], s)); h->merge_event = true; }
     }
     if (!record) return 0;
     if (h->timing_on) h->n_searches++;
@@ -411,7 +411,13 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
         const float* qb = qdev + (size_t)done * R.ld;
         // the scan merges its own per-block lists when a ticket counter per query tile is at hand
         const bool tail = h->tail_counters && p.grid_y <= ssmi_index::kTailCounters;
-        p.tail = TailMerge{tail ? h->tail_counters : nullptr, Ddev + (size_t)done * k, Idev + (size_t)done * k, id_offset};
+        p.tail = TailMerge{tail ? h->tail_counters : nullptr, Ddev + (size_t)done * k, Idev + (size_t)done * k, id_offset,
+                           nullptr, nullptr};
+        if (tail && h->plan_sizes && p.r == 1 && done == 0 && nb == nq) {  // IVF coarse quantizer: K7 rides along
+            p.tail.plan_sizes = h->plan_sizes;
+            p.tail.plan_prefix = h->plan_prefix;
+            h->plan_done = true;
+        }
         const bool rec = record && first && h->timing_on;
         if (rec) HIPCHECK(hipEventRecord(ev[0], s));
         if (R.dtype == SSMI_F32) HIPCHECK(launch_flat_scan_f32(R.view(), qb, (int)nb, k, partial, p, s));
@@ -420,7 +426,8 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
         if (!tail)
             HIPCHECK(launch_merge_keys(partial, (int)nb, p.grid_x, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
                                        id_offset, s));
-        if (rec) HIPCHECK(hipEventRecord(ev[2], s));
+        if (rec && !tail) HIPCHECK(hipEventRecord(ev[2], s));  // with a merge tail there is nothing between ev[1] and ev[2]
+        if (rec) h->merge_event = !tail;
         first = false;
         done += nb;
     }
@@ -539,9 +546,10 @@ int ssmi_index_get_timing(const ssmi_index* h, ssmi_timing* out) {
     float a = -1.f, b = -1.f;  // -1: the last search ran with timing switched off
     if (h->events_valid) {
         hipEvent_t const* ev = h->ev[(h->n_searches - 1) % ssmi_index::kEvRing];
-        HIPCHECK(hipEventSynchronize(ev[2]));
+        HIPCHECK(hipEventSynchronize(ev[h->merge_event ? 2 : 1]));
         HIPCHECK(hipEventElapsedTime(&a, ev[0], ev[1]));
-        HIPCHECK(hipEventElapsedTime(&b, ev[1], ev[2]));
+        b = 0.f;  // the scan merged its own lists (tail_merge.h): no separate merge launch
+        if (h->merge_event) HIPCHECK(hipEventElapsedTime(&b, ev[1], ev[2]));
     }
     t.last_scan_ms = a;
     t.last_merge_ms = b;

@@ -51,9 +51,15 @@ struct ssmi_index {
     bool timing_valid = false;
     bool timing_on = true;  // record the event triple of every search (ssmi_index_set_timing)
     bool events_valid = false;  // the last search recorded its events
+    bool merge_event = false;   // ... including the third one (a separate merge launch followed the scan)
     // ticket counters of the merge tails (tail_merge.h): zero between launches, one per query (tile)
     static const int kTailCounters = 4096;
     unsigned* tail_counters = nullptr;
+    // IVF: set around the coarse-quantizer search; a scan with a merge tail then also writes the probe plan
+    // (exclusive prefix sums of the probed lists' sizes) and reports it through plan_done
+    const int* plan_sizes = nullptr;
+    long long* plan_prefix = nullptr;
+    bool plan_done = false;
 
     // ---- IVF state (kind == SSMI_KIND_IVFFLAT) ----
     int nlist = 0, nprobe = 1;

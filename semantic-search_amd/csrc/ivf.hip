@@ -817,7 +817,12 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
         CHECK(ensure_ws(h, 7, (size_t)nb * nprobe * 8));
         CHECK(ensure_ws(h, 10, (size_t)nb * (nprobe + 1) * 8));
         const RowStore& C = (nb >= 9 && (S->cent16.ld % 64) == 0) ? S->cent16 : S->cent32;
-        CHECK(store_search(h, C, nb, qb, nprobe, (float*)h->ws[6], (int64_t*)h->ws[7], 0, s, false));
+        h->plan_sizes = list_major ? nullptr : S->d_size;
+        h->plan_prefix = (long long*)h->ws[10];
+        h->plan_done = false;
+        const int rc_coarse = store_search(h, C, nb, qb, nprobe, (float*)h->ws[6], (int64_t*)h->ws[7], 0, s, false);
+        h->plan_sizes = nullptr;
+        CHECK(rc_coarse);
         if (list_major) {
             CHECK(ensure_ws(h, 2, (size_t)nb * nprobe * k * sizeof(skey_t)));
             CHECK(ensure_ws(h, 11, (size_t)(4 * h->nlist + 3) * 4));
@@ -845,19 +850,22 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
             }
             HIPCHECK(launch_merge_keys((const skey_t*)h->ws[2], nb, nprobe, k, Ddev + (size_t)done * k,
                                        Idev + (size_t)done * k, id_offset, s));
-            if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[2], s));
+            if (h->timing_on && done == 0) { HIPCHECK(hipEventRecord(ev[2], s)); h->merge_event = true; }
             continue;
         }
-        hipLaunchKernelGGL(ivf_plan_kernel, dim3(nb), dim3(256), 0, s, (const int64_t*)h->ws[7], nprobe, S->d_size,
-                           (long long*)h->ws[10]);
-        HIPCHECK(hipGetLastError());
+        if (!h->plan_done) {
+            hipLaunchKernelGGL(ivf_plan_kernel, dim3(nb), dim3(256), 0, s, (const int64_t*)h->ws[7], nprobe, S->d_size,
+                               (long long*)h->ws[10]);
+            HIPCHECK(hipGetLastError());
+        }
         CHECK(ensure_ws(h, 2, (size_t)nb * gx * k * sizeof(skey_t)));
         IvfScanParams P;
         P.X = R.view(); P.Q = qb; P.Ic = (const int64_t*)h->ws[7]; P.prefix = (const long long*)h->ws[10];
         P.page_off = S->d_page_off; P.pages = S->d_pages; P.slot_ids = S->d_slot_ids; P.nprobe = nprobe; P.k = k;
         P.partial = (skey_t*)h->ws[2];
         const bool tail = h->tail_counters && nb <= ssmi_index::kTailCounters;
-        P.tail = TailMerge{tail ? h->tail_counters : nullptr, Ddev + (size_t)done * k, Idev + (size_t)done * k, id_offset};
+        P.tail = TailMerge{tail ? h->tail_counters : nullptr, Ddev + (size_t)done * k, Idev + (size_t)done * k, id_offset,
+                           nullptr, nullptr};
         if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[0], s));
 #define IVF_LAUNCH(TT, RR)                                                                                       \
     case RR: {                                                                                                   \
@@ -907,7 +915,8 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
         if (!tail)
             HIPCHECK(launch_merge_keys((const skey_t*)h->ws[2], nb, gx, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
                                        id_offset, s));
-        if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[2], s));
+        if (h->timing_on && done == 0 && !tail) HIPCHECK(hipEventRecord(ev[2], s));
+        if (h->timing_on && done == 0) h->merge_event = !tail;
     }
     if (h->timing_on) h->n_searches++;
     h->events_valid = h->timing_on;

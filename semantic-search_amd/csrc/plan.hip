@@ -57,7 +57,9 @@ bool plan_flat_scan(int dtype, int ld, long long nrows, int nq, int k, int num_c
     if (env_bpc) { int v = atoi(env_bpc); if (v >= 1 && v <= 16) blocks_per_cu = v; }
     const int nwaves = p->threads / 64;
     long long gx = (long long)num_cu * blocks_per_cu;
-    const long long max_useful = (nrows + (long long)nwaves * 4 - 1) / ((long long)nwaves * 4);
+    int min_rows = 1;  // rows per wave below which more blocks only add partial lists (the merge thins them cheaply)
+    if (const char* e = getenv("SSMI_SCAN_MINROWS")) { const int v = atoi(e); if (v >= 1 && v <= 64) min_rows = v; }
+    const long long max_useful = (nrows + (long long)nwaves * min_rows - 1) / ((long long)nwaves * min_rows);
     if (gx > max_useful) gx = max_useful;
     if (gx < 1) gx = 1;
     p->grid_x = (int)gx;

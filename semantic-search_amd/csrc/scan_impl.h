@@ -201,7 +201,8 @@ __global__ void __launch_bounds__(QREG ? (R <= 4 ? 768 : 512) : 1024) flat_scan_
         const int q = q0 + b;
         if (q >= nq) break;
         merge_partials<R, true>(partial + (size_t)q * gridDim.x * k, (int)gridDim.x, k, lds_keys, wave, nwaves,
-                          tail.D + (size_t)q * k, tail.I + (size_t)q * k, tail.id_offset);
+                          tail.D + (size_t)q * k, tail.I + (size_t)q * k, tail.id_offset, tail.plan_sizes,
+                          tail.plan_prefix ? tail.plan_prefix + (size_t)q * (k + 1) : nullptr);
         __syncthreads();
     }
 }

@@ -23,7 +23,26 @@ struct TailMerge {
     float* D;           // (nq, k)
     int64_t* I;         // (nq, k)
     int64_t id_offset;
+    // IVF coarse quantizer only (k = nprobe <= 64): the merged ids are the probed lists, and the block that
+    // merges them also writes the exclusive prefix sum of their sizes, (nq, k+1) int64 (K7's output)
+    const int* plan_sizes;
+    long long* plan_prefix;
 };
+
+// K7 folded into a merge: ids of the sorted list -> exclusive prefix sum of list sizes (one wave, k <= 64)
+__device__ __forceinline__ void write_plan(const WaveTopK<1>& t, int k, const int* sizes, long long* prefix) {
+    const int lane = lane_id();
+    const skey_t key = t.v[0];
+    const long long v = (lane < k && key != 0) ? (long long)sizes[key_id(key)] : 0;
+    long long incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long up = (long long)shfl_up64((skey_t)incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane < k) prefix[lane] = incl - v;
+    if (lane == k - 1) prefix[k] = incl;
+}
 
 template <int R>
 __device__ __forceinline__ void write_result(const WaveTopK<R>& t, int k, float* D, int64_t* I, int64_t id_offset) {
@@ -60,7 +79,8 @@ static constexpr int kMergeSurvivorCap = 256;
 // ~10 us, this form 2-3 us.  Inputs that defeat the bound (more than 256 survivors) take the full sort.
 template <int R, bool COHERENT>
 __device__ __forceinline__ void merge_partials(const skey_t* lists, int P, int k, skey_t* lds, int wave, int nwaves,
-                                               float* D, int64_t* I, int64_t id_offset) {
+                                               float* D, int64_t* I, int64_t id_offset, const int* plan_sizes = nullptr,
+                                               long long* plan_prefix = nullptr) {
     const int lane = lane_id();
     const int total = P * k;
     if (R == 1 && nwaves >= 5 && total > kMergeSurvivorCap) {
@@ -106,6 +126,7 @@ __device__ __forceinline__ void merge_partials(const skey_t* lists, int P, int k
                     t.v[0] = (unsigned)lane < n ? surv[lane] : 0;
                     t.sort_desc();
                     write_result<1>(t, k, D, I, id_offset);
+                    if (plan_sizes) write_plan(t, k, plan_sizes, plan_prefix);
                 } else {
                     WaveTopK<4> t;
 #pragma unroll
@@ -114,6 +135,7 @@ __device__ __forceinline__ void merge_partials(const skey_t* lists, int P, int k
                     WaveTopK<1> o;
                     o.v[0] = t.v[0];
                     write_result<1>(o, k, D, I, id_offset);
+                    if (plan_sizes) write_plan(o, k, plan_sizes, plan_prefix);
                 }
             }
             return;
@@ -151,7 +173,12 @@ __device__ __forceinline__ void merge_partials(const skey_t* lists, int P, int k
         for (int p = wave; p < P; p += nwaves) t.merge_from(lists + (size_t)p * k, k);
     }
     block_merge<R>(t, lds, wave, nwaves);
-    if (wave == 0) write_result<R>(t, k, D, I, id_offset);
+    if (wave == 0) {
+        write_result<R>(t, k, D, I, id_offset);
+        if constexpr (R == 1) {
+            if (plan_sizes) write_plan(t, k, plan_sizes, plan_prefix);
+        }
+    }
 }
 
 // Publishes a block's k-list to the other blocks of the launch: device-scope (write-through) stores,

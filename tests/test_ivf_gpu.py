@@ -225,3 +225,32 @@ def test_list_major_batched_scan_matches_oracle_and_per_query_scan(ssa, monkeypa
                 assert agree > 0.97, (nprobe, k, agree)
     monkeypatch.delenv("SSMI_IVF_LISTMAJOR")
     index.close()
+
+
+def test_batched_scan_is_repeatable_between_other_batches(ssa):
+    """The list-major MFMA scan (16-query groups: the register ring is deepest there) must return the same
+    bits every time, with another batch in between so that nothing of the previous pass survives in the
+    workspaces.  (A compiler-inserted copy of in-flight ring registers once made it differ run to run;
+    tests/test_ring_regs_cpu.py checks the assembly, this checks the behaviour.)"""
+    import torch
+    d, n, nlist, nq = 4096, 200_000, 256, 64
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(7)
+
+    def rows(m):
+        x = torch.randn((m, d), generator=g, device=dev)
+        return x / x.norm(dim=1, keepdim=True)
+
+    ivf = ssa.IndexIVFFlat(ssa.IndexFlatIP(d, storage="f16"), d, nlist, ssa.METRIC_INNER_PRODUCT, storage="f16")
+    ivf.train(rows(16 * nlist))
+    for s0 in range(0, n, 50_000):
+        ivf.add(rows(50_000))
+    ivf.nprobe = 8
+    Q, Q2 = rows(nq), rows(nq)
+    D0, I0 = ivf.search(Q, 10)
+    assert ivf.last_timing()["last_grid"] == -16
+    D0, I0 = D0.clone(), I0.clone()
+    for _ in range(5):
+        ivf.search(Q2, 10)
+        D, I = ivf.search(Q, 10)
+        assert torch.equal(I, I0) and torch.equal(D, D0)
