@@ -412,10 +412,12 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
         // the scan merges its own per-block lists when a ticket counter per query tile is at hand
         const bool tail = h->tail_counters && p.grid_y <= ssmi_index::kTailCounters;
         p.tail = TailMerge{tail ? h->tail_counters : nullptr, Ddev + (size_t)done * k, Idev + (size_t)done * k, id_offset,
-                           nullptr, nullptr};
+                           nullptr, nullptr, nullptr, nullptr};
         if (tail && h->plan_sizes && p.r == 1 && done == 0 && nb == nq) {  // IVF coarse quantizer: K7 rides along
             p.tail.plan_sizes = h->plan_sizes;
             p.tail.plan_prefix = h->plan_prefix;
+            p.tail.plan_page_off = h->plan_page_off;
+            p.tail.plan_po = h->plan_po;
             h->plan_done = true;
         }
         const bool rec = record && first && h->timing_on;

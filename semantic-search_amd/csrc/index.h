@@ -59,6 +59,8 @@ struct ssmi_index {
     // (exclusive prefix sums of the probed lists' sizes) and reports it through plan_done
     const int* plan_sizes = nullptr;
     long long* plan_prefix = nullptr;
+    const int* plan_page_off = nullptr;
+    int* plan_po = nullptr;
     bool plan_done = false;
 
     // ---- IVF state (kind == SSMI_KIND_IVFFLAT) ----

@@ -133,7 +133,7 @@ __global__ void split_centroid_kernel(int ld, void* const* segs32, int shift32, 
 // K7 (search side): per query, exclusive prefix sum of the probed lists' sizes.
 // prefix: (nq, nprobe+1) int64; one 256-thread block per query.
 __global__ void ivf_plan_kernel(const int64_t* __restrict__ Ic, int nprobe, const int* __restrict__ list_size,
-                                long long* __restrict__ prefix) {
+                                long long* __restrict__ prefix, const int* __restrict__ page_off, int* __restrict__ po) {
     __shared__ long long wsum[4];
     __shared__ long long carry;
     const int q = blockIdx.x;
@@ -145,7 +145,11 @@ __global__ void ivf_plan_kernel(const int64_t* __restrict__ Ic, int nprobe, cons
     for (int base = 0; base < nprobe; base += 256) {
         const int j = base + threadIdx.x;
         long long v = 0;
-        if (j < nprobe) { const int64_t l = ic[j]; v = (l >= 0) ? (long long)list_size[l] : 0; }
+        if (j < nprobe) {
+            const int64_t l = ic[j];
+            v = (l >= 0) ? (long long)list_size[l] : 0;
+            po[(size_t)q * nprobe + j] = (l >= 0) ? page_off[l] : 0;
+        }
         long long incl = v;  // inclusive scan inside the wave
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -169,6 +173,11 @@ struct IvfScanParams {
     const float* Q;             // (nq, ld) fp32
     const int64_t* Ic;          // (nq, nprobe) probed lists, best first
     const long long* prefix;    // (nq, nprobe+1)
+    const int* po;              // (nq, nprobe) page-table offsets of the probed lists (page_off[Ic])
+    int nsegs;                  // entries of X.segs
+#ifdef SSMI_IVF_STAMP
+    unsigned long long* dbg;    // diagnostic build: [wave][4] wall-clock stamps (100 MHz)
+#endif
     const int* page_off;        // nlist+1
     const int* pages;           // CSR payload
     const uint32_t* slot_ids;
@@ -276,13 +285,15 @@ __global__ void __launch_bounds__(256) ivf_scan_topk_kernel(IvfScanParams P) {
 
 // K8, register-query form for rows of NCH KiB (d = 4096: NCH 8 for fp16, 16 for fp32; also 2048, 1024):
 // the query lives in registers as in K1's batch-1 kernel, every chunk of a row is in flight before
-// the first FMA, fp16 rows are taken two at a time (16 KiB in flight per wave), and the page
+// the first FMA, and the page
 // number of a list position is looked up once per page, not once per row.  grid = (gx, nq),
 // blockDim = 64 * nwaves; one k-list per block.
-template <typename T, int NCH, int R>
-__global__ void __launch_bounds__(R <= 4 ? 768 : 512) ivf_scan_qreg_kernel(IvfScanParams P) {
+// ROWS = rows in flight per wave: 1 with 12 waves per CU (K1's shape), 2 with 8 waves per CU (a 768-thread block
+// with two rows in flight needs more than its 170 registers per lane: it spilled the query registers and
+// reloaded them between the row loads, which serialised the loads: 5.3 TB/s instead of 6.7).
+template <typename T, int NCH, int R, int ROWS>
+__global__ void __launch_bounds__((R <= 4 && ROWS == 1 && NCH * ElemTraits<T>::V <= 64) ? 768 : 512) ivf_scan_qreg_kernel(IvfScanParams P) {
     constexpr int V = ElemTraits<T>::V;
-    constexpr int ROWS = NCH <= 8 ? 2 : 1;
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -291,6 +302,9 @@ __global__ void __launch_bounds__(R <= 4 ? 768 : 512) ivf_scan_qreg_kernel(IvfSc
     const int ld = P.X.ld;
     constexpr int row_bytes = NCH * 1024;
 
+#ifdef SSMI_IVF_STAMP
+    unsigned long long st0 = wall_clock64(), st1 = 0, st2 = 0;
+#endif
     float qreg[NCH][V];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -302,9 +316,16 @@ __global__ void __launch_bounds__(R <= 4 ? 768 : 512) ivf_scan_qreg_kernel(IvfSc
         }
     }
 
+    // segment base pointers -> LDS: a wave-uniform lookup then costs an LDS read instead of a memory round trip
+    // in front of every page's row loads
+    const unsigned char** seg_l = reinterpret_cast<const unsigned char**>(smem + (size_t)nwaves * 64 * R * sizeof(skey_t));
+    for (int i = threadIdx.x; i < P.nsegs; i += blockDim.x) seg_l[i] = reinterpret_cast<const unsigned char*>(P.X.segs[i]);
     const long long* pf = P.prefix + (size_t)q * (P.nprobe + 1);
-    const int64_t* ic = P.Ic + (size_t)q * P.nprobe;
+    const int* po = P.po + (size_t)q * P.nprobe;
     const long long total = pf[P.nprobe];
+    __syncthreads();
+    // every wave owns a contiguous range of the probed rows (the waves of a block interleaving over a
+    // block range instead measured 30 % slower: fewer loads in flight per page chunk)
     const long long nw = (long long)gridDim.x * nwaves, wv = (long long)blockIdx.x * nwaves + wave;
     long long r = total * wv / nw;
     const long long r_hi = total * (wv + 1) / nw;
@@ -360,7 +381,7 @@ __global__ void __launch_bounds__(R <= 4 ? 768 : 512) ivf_scan_qreg_kernel(IvfSc
                     const bool in = jj < P.nprobe;
                     pf_lo = in ? pf[jj] : total;
                     pf_hi = in ? pf[jj + 1] : total;
-                    po_l = in ? P.page_off[ic[jj]] : 0;
+                    po_l = in ? po[jj] : 0;
                 } while (c0 + 64 < P.nprobe && r >= __shfl(pf_hi, 63));
             }
             // list of position r: the lane whose [pf_lo, pf_hi) contains it (empty lists never match)
@@ -371,14 +392,22 @@ __global__ void __launch_bounds__(R <= 4 ? 768 : 512) ivf_scan_qreg_kernel(IvfSc
             const long long lnext = (long long)readlane64((skey_t)pf_hi, j);
             const long long lend = lnext < r_hi ? lnext : r_hi;
             const int* lp = P.pages + __builtin_amdgcn_readlane(po_l, j);
+            const int np_list = (int)((lnext - base + kPageRows - 1) >> kPageShift);
+            int pi = (int)((r - base) >> kPageShift);
+            int pg = lp[pi];
+#ifdef SSMI_IVF_STAMP
+            if (st1 == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); st1 = wall_clock64(); }
+#endif
             while (r < lend) {
+                // the next page's number travels under this page's row loads: no dependent load at the page switch
+                const int pg_next = (pi + 1 < np_list) ? lp[pi + 1] : 0;
                 const long long o = r - base;
                 const int in_page = (int)(o & (kPageRows - 1));
                 long long cnt = kPageRows - in_page;
                 if (cnt > lend - r) cnt = lend - r;
-                const long long slot0 = (long long)lp[o >> kPageShift] * kPageRows + in_page;
+                const long long slot0 = (long long)pg * kPageRows + in_page;
                 // a page never straddles a segment (segment sizes are multiples of the page size)
-                const unsigned char* rowp = reinterpret_cast<const unsigned char*>(P.X.segs[slot0 >> P.X.seg_shift]) +
+                const unsigned char* rowp = seg_l[slot0 >> P.X.seg_shift] +
                                             (size_t)(slot0 & seg_mask) * (size_t)row_bytes + (size_t)lane * 16;
                 // ids of the page's rows: one coalesced load up front instead of a dependent load per
                 // candidate (a wave sees few rows, so most of them enter its still-short list)
@@ -388,9 +417,9 @@ __global__ void __launch_bounds__(R <= 4 ? 768 : 512) ivf_scan_qreg_kernel(IvfSc
                     for (; i + 2 <= (int)cnt; i += 2) {
                         uint4 x0[NCH], x1[NCH];
 #pragma unroll
-                        for (int c = 0; c < NCH; ++c) x0[c] = load16_nt(rowp + (size_t)i * row_bytes + c * 1024);
+                        for (int c = 0; c < NCH; ++c) x0[c] = load16_nt_g(rowp + (size_t)i * row_bytes + c * 1024);
 #pragma unroll
-                        for (int c = 0; c < NCH; ++c) x1[c] = load16_nt(rowp + (size_t)(i + 1) * row_bytes + c * 1024);
+                        for (int c = 0; c < NCH; ++c) x1[c] = load16_nt_g(rowp + (size_t)(i + 1) * row_bytes + c * 1024);
                         const float s0 = dot(x0);
                         const float s1 = dot(x1);
                         consider(s0, (uint32_t)__builtin_amdgcn_readlane(ids_l, i));
@@ -400,20 +429,34 @@ __global__ void __launch_bounds__(R <= 4 ? 768 : 512) ivf_scan_qreg_kernel(IvfSc
                 for (; i < (int)cnt; ++i) {
                     uint4 x0[NCH];
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) x0[c] = load16_nt(rowp + (size_t)i * row_bytes + c * 1024);
+                    for (int c = 0; c < NCH; ++c) x0[c] = load16_nt_g(rowp + (size_t)i * row_bytes + c * 1024);
                     consider(dot(x0), (uint32_t)__builtin_amdgcn_readlane(ids_l, i));
                 }
                 r += cnt;
+                ++pi;
+                pg = pg_next;
             }
         }
     }
+#ifdef SSMI_IVF_STAMP
+    st2 = wall_clock64();
+#endif
     skey_t* lds_keys = reinterpret_cast<skey_t*>(smem);
     block_merge<R>(top, lds_keys, wave, nwaves);
     if (wave == 0) publish_list<R>(top, P.partial + ((size_t)q * gridDim.x + blockIdx.x) * P.k, P.k);
+#ifdef SSMI_IVF_STAMP
+    if (lane == 0) {
+        unsigned long long* d = P.dbg + ((size_t)blockIdx.x * nwaves + wave) * 4;
+        d[0] = st0; d[1] = st1 ? st1 : st2; d[2] = st2; d[3] = wall_clock64();
+    }
+#endif
     if (P.tail.counter == nullptr) return;
     if (!tail_last_block(P.tail.counter + q, gridDim.x, reinterpret_cast<unsigned*>(lds_keys))) return;
     merge_partials<R, true>(P.partial + (size_t)q * gridDim.x * P.k, (int)gridDim.x, P.k, lds_keys, wave, nwaves,
                       P.tail.D + (size_t)q * P.k, P.tail.I + (size_t)q * P.k, P.tail.id_offset);
+#ifdef SSMI_IVF_STAMP
+    if (threadIdx.x == 0) P.dbg[(size_t)gridDim.x * nwaves * 4] = wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -774,6 +817,29 @@ int ivf_add_random_unit(ssmi_index* h, int64_t n, uint64_t seed) {
     return 0;
 }
 
+template <typename T, int NCH, int R, int ROWS>
+static hipError_t launch_qreg_rows(int gx, int nb, int threads, size_t lds, hipStream_t s, const IvfScanParams& P) {
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_scan_qreg_kernel<T, NCH, R, ROWS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((ivf_scan_qreg_kernel<T, NCH, R, ROWS>), dim3(gx, nb), dim3(threads), lds, s, P);
+    return hipGetLastError();
+}
+template <typename T, int NCH, int R>
+static hipError_t launch_qreg(int rows, int gx, int nb, int threads, size_t lds, hipStream_t s, const IvfScanParams& P) {
+    if constexpr (NCH <= 8) {
+        if (rows == 2) return launch_qreg_rows<T, NCH, R, 2>(gx, nb, threads, lds, s, P);
+    }
+    return launch_qreg_rows<T, NCH, R, 1>(gx, nb, threads, lds, s, P);
+}
+// threads per block of ivf_scan_qreg_kernel<T, NCH, R, ROWS> (its launch bound)
+static int qreg_threads(int dtype, int row_kib, int r, int rows) {
+    const int query_regs = dtype == SSMI_F32 ? row_kib * 4 : row_kib * 8;  // NCH * V
+    return (r <= 4 && rows == 1 && query_regs <= 64) ? 768 : 512;
+}
+
 int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev, int64_t* Idev, int64_t id_offset,
                hipStream_t s) {
     IvfState* S = st(h);
@@ -787,15 +853,18 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
     const int row_kib = (int)(R.row_bytes / 1024);
     const bool qreg = (R.row_bytes % 1024) == 0 && (row_kib == 1 || row_kib == 2 || row_kib == 4 || row_kib == 8 || row_kib == 16) &&
                       !getenv("SSMI_IVF_NO_QREG");
-    int qthreads = r <= 4 ? 768 : 512;
+    // rows in flight per wave of the register-query kernel: 2 (8 waves per CU) or 1 (12 waves per CU)
+    int qrows = 1;
+    if (const char* e = getenv("SSMI_IVF_ROWS")) qrows = atoi(e) == 2 ? 2 : 1;
+    if (row_kib > 8) qrows = 1;  // 16 KiB rows: one row already fills the load registers
+    const int qthreads = qreg_threads(R.dtype, row_kib, r, qrows);
     int qbpc = 1;  // blocks per CU for one query
-    if (const char* e = getenv("SSMI_IVF_QT")) qthreads = atoi(e);
     if (const char* e = getenv("SSMI_IVF_BPC")) qbpc = atoi(e);
     const int gx = qreg ? (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)h->num_cu * qbpc, ((int64_t)h->num_cu * 2 * qbpc + nq - 1) / nq))
                         : (int)std::max<int64_t>(1, std::min<int64_t>(1024, ((int64_t)h->num_cu * 6 + nq - 1) / nq));
     const int V = R.dtype == SSMI_F32 ? 4 : 8;
     const int ldq = (R.ld + 64 * V - 1) / (64 * V) * 64 * V;
-    const size_t lds = qreg ? (size_t)(qthreads / 64) * 64 * r * sizeof(skey_t)
+    const size_t lds = qreg ? (size_t)(qthreads / 64) * 64 * r * sizeof(skey_t) + R.segs.size() * sizeof(void*)
                             : std::max((size_t)ldq * 4, (size_t)4 * 64 * r * sizeof(skey_t));
     hipEvent_t* ev = h->ev[h->n_searches % ssmi_index::kEvRing];
     // batches whose probes revisit the lists (on average >= 2 probes per list) take the list-major scan
@@ -816,9 +885,12 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
         CHECK(ensure_ws(h, 6, (size_t)nb * nprobe * 4));
         CHECK(ensure_ws(h, 7, (size_t)nb * nprobe * 8));
         CHECK(ensure_ws(h, 10, (size_t)nb * (nprobe + 1) * 8));
+        CHECK(ensure_ws(h, 13, (size_t)nb * nprobe * 4));
         const RowStore& C = (nb >= 9 && (S->cent16.ld % 64) == 0) ? S->cent16 : S->cent32;
         h->plan_sizes = list_major ? nullptr : S->d_size;
         h->plan_prefix = (long long*)h->ws[10];
+        h->plan_page_off = S->d_page_off;
+        h->plan_po = (int*)h->ws[13];
         h->plan_done = false;
         const int rc_coarse = store_search(h, C, nb, qb, nprobe, (float*)h->ws[6], (int64_t*)h->ws[7], 0, s, false);
         h->plan_sizes = nullptr;
@@ -855,17 +927,22 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
         }
         if (!h->plan_done) {
             hipLaunchKernelGGL(ivf_plan_kernel, dim3(nb), dim3(256), 0, s, (const int64_t*)h->ws[7], nprobe, S->d_size,
-                               (long long*)h->ws[10]);
+                               (long long*)h->ws[10], S->d_page_off, (int*)h->ws[13]);
             HIPCHECK(hipGetLastError());
         }
         CHECK(ensure_ws(h, 2, (size_t)nb * gx * k * sizeof(skey_t)));
         IvfScanParams P;
         P.X = R.view(); P.Q = qb; P.Ic = (const int64_t*)h->ws[7]; P.prefix = (const long long*)h->ws[10];
+        P.po = (const int*)h->ws[13]; P.nsegs = (int)R.segs.size();
+#ifdef SSMI_IVF_STAMP
+        CHECK(ensure_ws(h, 14, ((size_t)gx * (qthreads / 64) * 4 + 1) * 8));
+        P.dbg = (unsigned long long*)h->ws[14];
+#endif
         P.page_off = S->d_page_off; P.pages = S->d_pages; P.slot_ids = S->d_slot_ids; P.nprobe = nprobe; P.k = k;
         P.partial = (skey_t*)h->ws[2];
         const bool tail = h->tail_counters && nb <= ssmi_index::kTailCounters;
         P.tail = TailMerge{tail ? h->tail_counters : nullptr, Ddev + (size_t)done * k, Idev + (size_t)done * k, id_offset,
-                           nullptr, nullptr};
+                           nullptr, nullptr, nullptr, nullptr};
         if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[0], s));
 #define IVF_LAUNCH(TT, RR)                                                                                       \
     case RR: {                                                                                                   \
@@ -877,10 +954,7 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
     }
 #define IVF_QLAUNCH(TT, NN, RR)                                                                                  \
     case RR: {                                                                                                   \
-        if (lds > 48 * 1024)                                                                                     \
-            HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_scan_qreg_kernel<TT, NN, RR>),       \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
-        hipLaunchKernelGGL((ivf_scan_qreg_kernel<TT, NN, RR>), dim3(gx, nb), dim3(qthreads), lds, s, P);        \
+        HIPCHECK((launch_qreg<TT, NN, RR>(qrows, gx, nb, qthreads, lds, s, P)));                                 \
         break;                                                                                                   \
     }
 #define IVF_QLAUNCH_R(TT, NN)                                                                                    \
@@ -915,6 +989,26 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
         if (!tail)
             HIPCHECK(launch_merge_keys((const skey_t*)h->ws[2], nb, gx, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
                                        id_offset, s));
+#ifdef SSMI_IVF_STAMP
+        if (qreg && getenv("SSMI_IVF_STAMP_PRINT")) {
+            HIPCHECK(hipStreamSynchronize(s));
+            const size_t nwv = (size_t)gx * (qthreads / 64);
+            std::vector<unsigned long long> d(nwv * 4 + 1);
+            HIPCHECK(hipMemcpy(d.data(), h->ws[14], d.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull;
+            for (size_t w = 0; w < nwv; ++w) t0 = std::min(t0, d[w * 4]);
+            double sum[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0}, mn[4] = {1e30, 1e30, 1e30, 1e30};
+            for (size_t w = 0; w < nwv; ++w)
+                for (int i = 0; i < 4; ++i) {
+                    const double us = (double)(d[w * 4 + i] - t0) * 0.01;
+                    sum[i] += us; mx[i] = std::max(mx[i], us); mn[i] = std::min(mn[i], us);
+                }
+            fprintf(stderr, "[ivf stamp] us since first wave start (min/mean/max over %zu waves): start %.1f/%.1f/%.1f  first row load %.1f/%.1f/%.1f  "
+                            "rows done %.1f/%.1f/%.1f  list published %.1f/%.1f/%.1f  merged %.1f\n", nwv,
+                    mn[0], sum[0] / nwv, mx[0], mn[1], sum[1] / nwv, mx[1], mn[2], sum[2] / nwv, mx[2], mn[3], sum[3] / nwv, mx[3],
+                    (double)(d[nwv * 4] - t0) * 0.01);
+        }
+#endif
         if (h->timing_on && done == 0 && !tail) HIPCHECK(hipEventRecord(ev[2], s));
         if (h->timing_on && done == 0) h->merge_event = !tail;
     }

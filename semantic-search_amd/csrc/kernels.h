@@ -15,7 +15,7 @@ struct ScanPlan {
     int grid_x;    // row slices == partial lists per query
     int grid_y;    // query tiles
     size_t lds;    // dynamic LDS bytes
-    TailMerge tail = {nullptr, nullptr, nullptr, 0, nullptr, nullptr};  // counter set: the scan writes (D, I) itself, no K3 launch
+    TailMerge tail = {nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};  // counter set: the scan writes (D, I) itself, no K3 launch
 };
 
 // K1 planning + launch

@@ -36,6 +36,14 @@ __device__ __forceinline__ uint4 load16_nt(const void* p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// the same through an explicitly global pointer (a row pointer that was read from LDS or memory is a flat
+// pointer to the compiler, and flat loads also tick the LDS counter)
+__device__ __forceinline__ uint4 load16_nt_g(const void* p) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) u32x4_t*>(
+        reinterpret_cast<uintptr_t>(p)));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 template <typename T> struct Unpack;
 template <> struct Unpack<float> {
     __device__ __forceinline__ static void run(const uint4& x, float* f) {
@@ -201,8 +209,9 @@ __global__ void __launch_bounds__(QREG ? (R <= 4 ? 768 : 512) : 1024) flat_scan_
         const int q = q0 + b;
         if (q >= nq) break;
         merge_partials<R, true>(partial + (size_t)q * gridDim.x * k, (int)gridDim.x, k, lds_keys, wave, nwaves,
-                          tail.D + (size_t)q * k, tail.I + (size_t)q * k, tail.id_offset, tail.plan_sizes,
-                          tail.plan_prefix ? tail.plan_prefix + (size_t)q * (k + 1) : nullptr);
+                          tail.D + (size_t)q * k, tail.I + (size_t)q * k, tail.id_offset,
+                          PlanOut{tail.plan_sizes, tail.plan_sizes ? tail.plan_prefix + (size_t)q * (k + 1) : nullptr,
+                                  tail.plan_page_off, tail.plan_sizes ? tail.plan_po + (size_t)q * k : nullptr});
         __syncthreads();
     }
 }

@@ -27,13 +27,25 @@ struct TailMerge {
     // merges them also writes the exclusive prefix sum of their sizes, (nq, k+1) int64 (K7's output)
     const int* plan_sizes;
     long long* plan_prefix;
+    const int* plan_page_off;  // CSR offsets of the lists' page tables ...
+    int* plan_po;              // ... gathered for the probed lists, (nq, k) int32
 };
 
 // K7 folded into a merge: ids of the sorted list -> exclusive prefix sum of list sizes (one wave, k <= 64)
-__device__ __forceinline__ void write_plan(const WaveTopK<1>& t, int k, const int* sizes, long long* prefix) {
+struct PlanOut {
+    const int* sizes;
+    long long* prefix;
+    const int* page_off;
+    int* po;
+};
+__device__ __forceinline__ void write_plan(const WaveTopK<1>& t, int k, const PlanOut& pl) {
     const int lane = lane_id();
     const skey_t key = t.v[0];
-    const long long v = (lane < k && key != 0) ? (long long)sizes[key_id(key)] : 0;
+    const int* sizes = pl.sizes;
+    long long* prefix = pl.prefix;
+    const bool have = lane < k && key != 0;
+    const long long v = have ? (long long)sizes[key_id(key)] : 0;
+    if (lane < k) pl.po[lane] = have ? pl.page_off[key_id(key)] : 0;
     long long incl = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -79,8 +91,8 @@ static constexpr int kMergeSurvivorCap = 256;
 // ~10 us, this form 2-3 us.  Inputs that defeat the bound (more than 256 survivors) take the full sort.
 template <int R, bool COHERENT>
 __device__ __forceinline__ void merge_partials(const skey_t* lists, int P, int k, skey_t* lds, int wave, int nwaves,
-                                               float* D, int64_t* I, int64_t id_offset, const int* plan_sizes = nullptr,
-                                               long long* plan_prefix = nullptr) {
+                                               float* D, int64_t* I, int64_t id_offset,
+                                               PlanOut plan = PlanOut{nullptr, nullptr, nullptr, nullptr}) {
     const int lane = lane_id();
     const int total = P * k;
     if (R == 1 && nwaves >= 5 && total > kMergeSurvivorCap) {
@@ -126,7 +138,7 @@ __device__ __forceinline__ void merge_partials(const skey_t* lists, int P, int k
                     t.v[0] = (unsigned)lane < n ? surv[lane] : 0;
                     t.sort_desc();
                     write_result<1>(t, k, D, I, id_offset);
-                    if (plan_sizes) write_plan(t, k, plan_sizes, plan_prefix);
+                    if (plan.sizes) write_plan(t, k, plan);
                 } else {
                     WaveTopK<4> t;
 #pragma unroll
@@ -135,7 +147,7 @@ __device__ __forceinline__ void merge_partials(const skey_t* lists, int P, int k
                     WaveTopK<1> o;
                     o.v[0] = t.v[0];
                     write_result<1>(o, k, D, I, id_offset);
-                    if (plan_sizes) write_plan(o, k, plan_sizes, plan_prefix);
+                    if (plan.sizes) write_plan(o, k, plan);
                 }
             }
             return;
@@ -176,7 +188,7 @@ __device__ __forceinline__ void merge_partials(const skey_t* lists, int P, int k
     if (wave == 0) {
         write_result<R>(t, k, D, I, id_offset);
         if constexpr (R == 1) {
-            if (plan_sizes) write_plan(t, k, plan_sizes, plan_prefix);
+            if (plan.sizes) write_plan(t, k, plan);
         }
     }
 }
