@@ -829,7 +829,7 @@ static hipError_t launch_qreg_rows(int gx, int nb, int threads, size_t lds, hipS
 }
 template <typename T, int NCH, int R>
 static hipError_t launch_qreg(int rows, int gx, int nb, int threads, size_t lds, hipStream_t s, const IvfScanParams& P) {
-    if constexpr (NCH <= 8) {
+    if constexpr (NCH <= 8 && R <= 8) {  // (16 KiB rows and k > 512 do not leave room for a second row)
         if (rows == 2) return launch_qreg_rows<T, NCH, R, 2>(gx, nb, threads, lds, s, P);
     }
     return launch_qreg_rows<T, NCH, R, 1>(gx, nb, threads, lds, s, P);
@@ -856,7 +856,7 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
     // rows in flight per wave of the register-query kernel: 2 (8 waves per CU) or 1 (12 waves per CU)
     int qrows = 1;
     if (const char* e = getenv("SSMI_IVF_ROWS")) qrows = atoi(e) == 2 ? 2 : 1;
-    if (row_kib > 8) qrows = 1;  // 16 KiB rows: one row already fills the load registers
+    if (row_kib > 8 || r > 8) qrows = 1;  // 16 KiB rows, k > 512: one row already fills the registers
     const int qthreads = qreg_threads(R.dtype, row_kib, r, qrows);
     int qbpc = 1;  // blocks per CU for one query
     if (const char* e = getenv("SSMI_IVF_BPC")) qbpc = atoi(e);

@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(1024) ivf_scan_lists_kernel(IvfListScanArgs A)
         float acc[BT][4];
 #pragma unroll
         for (int b = 0; b < BT; ++b) acc[b][0] = acc[b][1] = acc[b][2] = acc[b][3] = 0.f;
-        constexpr int G = BT >= 8 ? 4 : 8;
+        constexpr int G = BT >= 8 ? (V == 8 ? 1 : 4) : 8;  // 8 queries x 8 elements per 16 B: one chunk keeps fp16 rows inside the register budget
 #pragma unroll 1
         for (int c0 = 0; c0 < nch; c0 += G) {
             uint4 x[G];

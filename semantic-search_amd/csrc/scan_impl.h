@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(QREG ? (R <= 4 ? 768 : 512) : 1024) flat_scan_
         } else {
             // G chunks in flight per wave; queries come from LDS (one conflict-free
             // ds_read_b128 per query per 16 B of row data)
-            constexpr int G = BT >= 8 ? 4 : 8;
+            constexpr int G = BT >= 8 ? (V == 8 ? 1 : 4) : 8;  // 8 queries x 8 elements per 16 B: one chunk keeps fp16 rows inside the register budget
             const int row_bytes = ld * (int)sizeof(T);
 #pragma unroll 1
             for (int c0 = 0; c0 < nch; c0 += G) {
