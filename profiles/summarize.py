@@ -86,4 +86,4 @@ pmc("mfma_f16_1M_b4096", [f"prof_{tag}_mfma_pmc_sq", f"prof_{tag}_mfma_pmc_lds",
     "Flat IP 1000000x4096 f16, batch 4096, k=10", ["flat_mfma_pp_kernel"])
 pmc("ivf_f16_2M_b1", [f"prof_{tag}_ivf_pmc_FETCH_SIZE", f"prof_{tag}_ivf_pmc_WRITE_SIZE"],
     "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate runs) -- python3 tools/prof_ivf.py 2000000 4096 1024 16",
-    "IVF1024 nprobe=16 over 2000000x4096 f16, batch 1, k=10", ["ivf_scan_topk_kernel", "flat_scan_topk_kernel", "ivf_plan_kernel"])
+    "IVF1024 nprobe=16 over 2000000x4096 f16, batch 1, k=10", ["ivf_scan_qreg_kernel", "ivf_scan_topk_kernel", "flat_scan_topk_kernel", "ivf_plan_kernel"])
