@@ -152,6 +152,23 @@ def cpu_baseline(index, d, k, sample_rows, queries):
     n = min(sample_rows, index.ntotal)
     X = index.reconstruct_n(0, n)
     Q = queries[:4].cpu().numpy()
+    try:  # the reference's own engine, if this machine has it; the build image does not
+        import faiss
+    except Exception:
+        faiss = None
+    if faiss is not None:
+        ref = faiss.IndexFlatIP(d)
+        ref.add(X)
+        ref.search(Q[:1], k)
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 10.0 and reps < 64:
+            for i in range(Q.shape[0]):
+                ref.search(Q[i:i + 1], k)  # batch 1, as core/index_manager.py:371 calls it
+            reps += 1
+        dt = time.perf_counter() - t0
+        return {"value": reps * Q.shape[0] / dt, "unit": "queries/s", "cores": faiss.omp_get_max_threads(), "kind": "reference",
+                "sample": f"faiss {faiss.__version__} IndexFlatIP on the first {n} rows x {d} fp32 of the same database, "
+                          f"{reps * Q.shape[0]} batch-1 queries, k={k}; linear extrapolation to the full database = value * {n}/N"}
     c_oracle.search(X[:1000], Q[:1], k)  # load + warm
     reps, t0 = 0, time.perf_counter()
     while True:
