@@ -191,6 +191,18 @@ class SemanticIndex:
                 self._training_buffer, self._training_buffer_size = [np.ascontiguousarray(buf, dtype=np.float32)], len(buf)
 
     # -- load / create / save -------------------------------------------------
+    @property
+    def _faiss_index(self):
+        return self.__dict__.get("_engine")
+
+    @_faiss_index.setter
+    def _faiss_index(self, index) -> None:
+        # every engine index bound to a SemanticIndex serves searches and is never timed: no per-search event
+        # records (each costs the stream ~6 us)
+        self.__dict__["_engine"] = index
+        if index is not None and hasattr(index, "set_timing"):
+            index.set_timing(False)
+
     def _load_or_create_faiss(self) -> None:
         """:181-214"""
         params = self._config.get("index_params", {})
