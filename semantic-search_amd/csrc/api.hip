@@ -343,7 +343,10 @@ static int mfma_min_batch(int dtype) {
 
 static int store_search_mfma(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev, int k, float* Ddev,
                              int64_t* Idev, int64_t id_offset, hipStream_t s, bool record) {
-    const int64_t kMaxBatch = 4096;  // 16 query tiles -> 16 database slices on 256 CUs
+    // 16 query tiles -> 16 database slices on 256 CUs.  A small store (an IVF coarse quantizer: add and k-means
+    // assign 65536 vectors at a time) is walked whole by every workgroup instead: one pass with 256 query
+    // tiles, not 16 passes of one row tile per workgroup
+    const int64_t kMaxBatch = R.nrows <= 65536 ? 65536 : 4096;
     hipEvent_t* ev = h->ev[h->n_searches % ssmi_index::kEvRing];
     MfmaPlan p = {};
     for (int64_t done = 0; done < nq; done += kMaxBatch) {
