@@ -19,7 +19,8 @@ def test_oracle_flat_matches_faiss():
     index.add(X)
     D, I = index.search(Q, 10)
     Do, Io = flat_ip.search(X, Q, 10)
-    flat_ip.check_against(D, I, Do, Io, X, Q)
+    ok, msg, _ = flat_ip.check_against(Do, Io, D, I, X, Q)
+    assert ok, msg
     D, I = index.search(Q[:3], 20_000)                                 # k > ntotal: -1 / -FLT_MAX padding
     assert (I[:, 10_000:] == -1).all() and (D[:, 10_000:] == flat_ip.NEG_MAX).all()
 
@@ -35,8 +36,9 @@ def test_oracle_ivf_matches_faiss_given_its_centroids():
     for nprobe in (1, 10, nlist):
         index.nprobe = nprobe
         D, I = index.search(Q, 10)
-        Do, Io = ivf_flat.search(X, C, labels, Q, 10, nprobe)
-        flat_ip.check_against(D, I, Do, Io, X, Q)
+        Do, Io, _ = ivf_flat.search(X, C, labels, Q, 10, nprobe)
+        ok, msg, _ = flat_ip.check_against(Do, Io, D, I, X, Q)
+        assert ok, f"nprobe={nprobe}: {msg}"
 
 
 @pytest.mark.gpu
@@ -48,4 +50,5 @@ def test_hip_flat_matches_faiss(ssa):
     ours = ssa.IndexFlatIP(4096)
     ours.add(X)
     Dg, Ig = ours.search(Q[:1], 10)
-    flat_ip.check_against(Dg, Ig, D, I, X, Q[:1])
+    ok, msg, _ = flat_ip.check_against(Dg, Ig, D, I, X, Q[:1])
+    assert ok, msg

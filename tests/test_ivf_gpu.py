@@ -254,3 +254,27 @@ def test_batched_scan_is_repeatable_between_other_batches(ssa):
         ivf.search(Q2, 10)
         D, I = ivf.search(Q, 10)
         assert torch.equal(I, I0) and torch.equal(D, D0)
+
+
+@pytest.mark.parametrize("no_tail", ["", "1"])
+def test_many_probes_and_both_merge_forms(ssa, monkeypatch, no_tail):
+    """nprobe > 64: the coarse quantizer's merge keeps lists of more than 64 keys, so the probe plan comes from
+    the separate planning kernel instead of the merge tail; SSMI_NO_TAIL=1: the scans leave every merge to K3."""
+    if no_tail:
+        monkeypatch.setenv("SSMI_NO_TAIL", no_tail)
+    n, d, nlist = 12_000, 512, 200
+    X, C = clustered_rows(n, d, nlist, 41), clustered_rows(nlist, d, nlist, 42)
+    index = make_ivf(ssa, d, nlist)
+    index.set_centroids(C)
+    index.add(X)
+    labels = index.assignments()
+    for nq in (1, 5):
+        Q = clustered_rows(nq, d, nlist, 43 + nq)
+        for nprobe, k in ((20, 10), (100, 10), (150, 70), (200, 300)):
+            index.nprobe = nprobe
+            D, I = index.search(Q, k)
+            assert index.last_timing()["last_grid"] > 0  # per-query scan
+            Dr, Ir, _ = ivf_flat.search(X, C, labels, Q, k, nprobe)
+            ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, X, Q, rtol=1e-5, tie_rtol=1e-5)
+            assert ok, f"nq={nq} nprobe={nprobe} k={k}: {msg}"
+    index.close()
