@@ -380,7 +380,7 @@ namespace ssmi {
 // for small batches, K2 (MFMA) for large batches over fp16 rows; K3 merges.
 // record = false: no events/timing (used for the IVF coarse quantizer).
 int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev /*(nq,ld)*/, int k, float* Ddev,
-                 int64_t* Idev, int64_t id_offset, hipStream_t s, bool record) {
+                 int64_t* Idev, int64_t id_offset, hipStream_t s, bool record, ProbePlanRequest* plan) {
     if (R.dtype == SSMI_F16 && (R.ld % 64) == 0 && nq >= mfma_min_batch(SSMI_F16))
         return store_search_mfma(h, R, nq, qdev, k, Ddev, Idev, id_offset, s, record);
     if (&R == &h->rows && h->kind == SSMI_KIND_FLAT && R.dtype == SSMI_F32 && (R.ld % 64) == 0 &&
@@ -416,12 +416,12 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
         const bool tail = h->tail_counters && p.grid_y <= ssmi_index::kTailCounters;
         p.tail = TailMerge{tail ? h->tail_counters : nullptr, Ddev + (size_t)done * k, Idev + (size_t)done * k, id_offset,
                            nullptr, nullptr, nullptr, nullptr};
-        if (tail && h->plan_sizes && p.r == 1 && done == 0 && nb == nq) {  // IVF coarse quantizer: K7 rides along
-            p.tail.plan_sizes = h->plan_sizes;
-            p.tail.plan_prefix = h->plan_prefix;
-            p.tail.plan_page_off = h->plan_page_off;
-            p.tail.plan_po = h->plan_po;
-            h->plan_done = true;
+        if (tail && plan && p.r == 1 && done == 0 && nb == nq) {  // IVF coarse quantizer: K7 rides along
+            p.tail.plan_sizes = plan->sizes;
+            p.tail.plan_prefix = plan->prefix;
+            p.tail.plan_page_off = plan->page_off;
+            p.tail.plan_po = plan->po;
+            plan->done = true;
         }
         const bool rec = record && first && h->timing_on;
         if (rec) HIPCHECK(hipEventRecord(ev[0], s));

@@ -55,13 +55,6 @@ struct ssmi_index {
     // ticket counters of the merge tails (tail_merge.h): zero between launches, one per query (tile)
     static const int kTailCounters = 4096;
     unsigned* tail_counters = nullptr;
-    // IVF: set around the coarse-quantizer search; a scan with a merge tail then also writes the probe plan
-    // (exclusive prefix sums of the probed lists' sizes) and reports it through plan_done
-    const int* plan_sizes = nullptr;
-    long long* plan_prefix = nullptr;
-    const int* plan_page_off = nullptr;
-    int* plan_po = nullptr;
-    bool plan_done = false;
 
     // ---- IVF state (kind == SSMI_KIND_IVFFLAT) ----
     int nlist = 0, nprobe = 1;
@@ -103,8 +96,18 @@ int ensure_ws(ssmi_index* h, int slot, size_t bytes);
 // query staging shared by the flat and IVF paths: returns (nq, ld) fp32 on device
 int stage_queries(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind, hipStream_t s, const float** out);
 
+// IVF coarse quantizer: a scan that merges its own lists (tail_merge.h) can also write the probe plan of every
+// query (exclusive prefix sums of the probed lists' sizes and their page-table offsets); `done` reports whether
+// it did, otherwise the caller runs the planning kernel
+struct ProbePlanRequest {
+    const int* sizes;
+    long long* prefix;
+    const int* page_off;
+    int* po;
+    bool done;
+};
 int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev, int k, float* Ddev, int64_t* Idev,
-                 int64_t id_offset, hipStream_t s, bool record);
+                 int64_t id_offset, hipStream_t s, bool record, ProbePlanRequest* plan = nullptr);
 
 // IVF entry points (ivf.hip)
 int ivf_create(ssmi_index* h, int nlist);

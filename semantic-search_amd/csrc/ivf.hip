@@ -887,14 +887,8 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
         CHECK(ensure_ws(h, 10, (size_t)nb * (nprobe + 1) * 8));
         CHECK(ensure_ws(h, 13, (size_t)nb * nprobe * 4));
         const RowStore& C = (nb >= 9 && (S->cent16.ld % 64) == 0) ? S->cent16 : S->cent32;
-        h->plan_sizes = list_major ? nullptr : S->d_size;
-        h->plan_prefix = (long long*)h->ws[10];
-        h->plan_page_off = S->d_page_off;
-        h->plan_po = (int*)h->ws[13];
-        h->plan_done = false;
-        const int rc_coarse = store_search(h, C, nb, qb, nprobe, (float*)h->ws[6], (int64_t*)h->ws[7], 0, s, false);
-        h->plan_sizes = nullptr;
-        CHECK(rc_coarse);
+        ProbePlanRequest plan = {S->d_size, (long long*)h->ws[10], S->d_page_off, (int*)h->ws[13], false};
+        CHECK(store_search(h, C, nb, qb, nprobe, (float*)h->ws[6], (int64_t*)h->ws[7], 0, s, false, list_major ? nullptr : &plan));
         if (list_major) {
             CHECK(ensure_ws(h, 2, (size_t)nb * nprobe * k * sizeof(skey_t)));
             CHECK(ensure_ws(h, 11, (size_t)(4 * h->nlist + 3) * 4));
@@ -925,7 +919,7 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
             if (h->timing_on && done == 0) { HIPCHECK(hipEventRecord(ev[2], s)); h->merge_event = true; }
             continue;
         }
-        if (!h->plan_done) {
+        if (!plan.done) {
             hipLaunchKernelGGL(ivf_plan_kernel, dim3(nb), dim3(256), 0, s, (const int64_t*)h->ws[7], nprobe, S->d_size,
                                (long long*)h->ws[10], S->d_page_off, (int*)h->ws[13]);
             HIPCHECK(hipGetLastError());
