@@ -27,6 +27,8 @@ def r16(a):
     (2000, 1024, 16, 500),
     (300, 4096, 20, 1024),    # k > n: padding
     (70000, 512, 12, 10),     # many row tiles per slice -> threshold path exercised
+    (30000, 2048, 50, 10),    # Matryoshka truncations on the register-streaming kernel: 64-query form ...
+    (8000, 1024, 120, 64),    # ... and 128-query form
 ])
 def test_mfma_matches_oracle_on_rounded_operands(ssa, n, d, nq, k):
     X, Q = unit_rows(n, d, 1234), unit_rows(nq, d, 4321)
