@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--storage", default="f32", choices=["f32", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the batch-1024/4096 MFMA side measurements")
+    ap.add_argument("--no-ivf-extra", action="store_true", help="skip the IVF4096 / 10M-row side measurement (configs[3])")
     ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
     ap.add_argument("--workload", default="flat", choices=["flat", "ivf"],
                     help="flat = BASELINE configs[1] (the default bench line); ivf = configs[3] (IVF4096, nprobe 32; 1 GPU)")
@@ -51,7 +52,7 @@ def parse():
     return ap.parse_args()
 
 
-def run_ivf(args):
+def run_ivf(args, emit=True):
     """BASELINE configs[3]: IVF<nlist> nprobe=<nprobe> over n x d f16 rows on one GPU: coarse-quantizer
     training, add, batch-1 and batch-1000 search, recall@10 against the Flat index over the same rows."""
     import semantic_search_amd as ssa
@@ -143,7 +144,10 @@ def run_ivf(args):
                   "batch_1000_qps": 1000 / t_b, "batch_4096_qps": 4096 / t_b4, "recall_at_%d_vs_flat" % k: recall,
                   "recall_note": "1000 queries; ground truth = IndexFlatIP (f16 rows) over the same vectors"},
     }
-    print(json.dumps(line), flush=True)
+    ivf.close(); flat.close()
+    if emit:
+        print(json.dumps(line), flush=True)
+    return line
 
 
 def cpu_baseline(index, d, k, sample_rows, queries):
@@ -338,6 +342,24 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(index.local, args.d, args.k, args.cpu_sample_rows, Q[0].expand(4, -1) if args.batch == 1 else Q[0])
             line["cpu_baseline"]["extrapolated_full_db_qps"] = line["cpu_baseline"]["value"] * min(args.cpu_sample_rows, n_local) / args.n
+        if world == 1 and not args.no_extra and not args.no_ivf_extra:
+            # side measurement (not `value`): BASELINE configs[3], IVF4096 nprobe 32 over 10M x 4096 f16 rows, the same
+            # procedure as `bench.py --workload ivf`; needs ~170 GB of HBM next to the flat index
+            try:
+                index.local.close()
+                free_b, _ = torch.cuda.mem_get_info()
+                if free_b > 200 * (1 << 30):
+                    import copy
+                    a2 = copy.copy(args)
+                    a2.n, a2.steps, a2.warmup, a2.ivf_data, a2.ivf_sorted = 10_000_000, 200, 10, "clustered", False
+                    iv = run_ivf(a2, emit=False)
+                    extra["ivf_c4"] = {"workload": iv["config"]["workload"], "batch_1_qps": iv["value"],
+                                       "scan_kernel_hbm_frac": iv["roofline"]["frac"], "scan_kernel_ms": iv["roofline"]["kernel_avg_ms"],
+                                       "probed_bytes_per_query": iv["roofline"]["algorithmic_bytes_per_launch"], **iv["extra"]}
+                else:
+                    extra["ivf_c4"] = {"skipped": "less than 200 GiB of HBM free"}
+            except Exception as e:  # the side measurement must never take the bench line down
+                extra["ivf_c4"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
