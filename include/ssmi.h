@@ -134,6 +134,11 @@ int ssmi_index_make_direct_map(ssmi_index* h);
 /* ---- persistence -------------------------------------------------------- */
 /* replaces faiss.write_index(index, path)          core/index_manager.py:241 */
 int ssmi_index_write(ssmi_index* h, const char* path);
+/* same file, written incrementally: if `path` holds an earlier state of this Flat index (a prefix of its rows)
+ * only the rows added since are appended and the header counts patched - byte-identical to ssmi_index_write,
+ * at O(new rows) instead of O(N) per checkpoint (the reference rewrites the whole index every 10 batches,
+ * core/index_manager.py:859-860 -> :241).  Anything else falls back to the full write.  SURVEY.md 8f rank 4. */
+int ssmi_index_write_append(ssmi_index* h, const char* path);
 /* replaces faiss.read_index(path)                  core/index_manager.py:185 */
 int ssmi_index_read(const char* path, int storage_dtype, int device, ssmi_index** out);
 

@@ -67,6 +67,7 @@ _SIGNATURES = {
     "ssmi_index_reconstruct_n": [_c_index_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p],
     "ssmi_index_make_direct_map": [_c_index_p],
     "ssmi_index_write": [_c_index_p, ctypes.c_char_p],
+    "ssmi_index_write_append": [_c_index_p, ctypes.c_char_p],
     "ssmi_index_read": [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_c_index_p)],
     "ssmi_index_get_timing": [_c_index_p, ctypes.POINTER(Timing)],
     "ssmi_index_get_scan_times": [_c_index_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)],

@@ -1250,6 +1250,64 @@ int ssmi_index_write(ssmi_index* h, const char* path) {
     return 0;
 }
 
+// Checkpoint of a growing Flat index: when `path` already holds an earlier state of THIS index (same d, a
+// prefix of its rows - checked on the header, the file size and the last stored row), only the rows added since
+// are appended and the two counts in the header are patched; the result is byte-identical to ssmi_index_write.
+// Anything else (no file, another index, an IVF index) is a full rewrite.  The reference rewrites the whole file
+// at every checkpoint (core/index_manager.py:859-860 -> :241): N*d*4 bytes each time.
+int ssmi_index_write_append(ssmi_index* h, const char* path) {
+    if (!h || !path) return fail("NULL argument");
+    if (h->kind != SSMI_KIND_FLAT) return ssmi_index_write(h, path);
+    DeviceGuard g(h->device);
+    const RowStore& R = h->rows;
+    const long kHeader = 4 + 33;  // fourcc + header; then n_floats:u64, then the rows
+    int64_t have = -1;
+    {
+        File F;
+        F.f = fopen(path, "rb");
+        if (F.f) {
+            char cc[4];
+            int d = 0; int64_t nt = 0; bool tr = false; uint64_t nfl = 0;
+            if (rd(F.f, cc, 4) && memcmp(cc, "IxFI", 4) == 0 && read_header(F.f, &d, &nt, &tr) == 0 && rd1(F.f, &nfl) &&
+                d == R.d && nt <= R.nrows && nfl == (uint64_t)nt * (uint64_t)d && fseek(F.f, 0, SEEK_END) == 0 &&
+                (uint64_t)ftell(F.f) == (uint64_t)kHeader + 8 + nfl * 4) {
+                have = nt;
+                if (nt > 0) {  // the last stored row must be row nt-1 of this index
+                    std::vector<float> on_disk((size_t)d), ours((size_t)d);
+                    const int64_t id = nt - 1;
+                    if (fseek(F.f, kHeader + 8 + (long)((uint64_t)id * d * 4), SEEK_SET) != 0 || !rd(F.f, on_disk.data(), (size_t)d * 4)) have = -1;
+                    else {
+                        CHECK(read_rows(h, R, R.nrows, &id, 1, ours.data()));
+                        if (memcmp(on_disk.data(), ours.data(), (size_t)d * 4) != 0) have = -1;
+                    }
+                }
+            }
+        }
+    }
+    if (have < 0) return ssmi_index_write(h, path);
+    if (have == R.nrows) return 0;  // nothing new
+    File F;
+    F.f = fopen(path, "r+b");
+    if (!F.f) return ssmi_index_write(h, path);
+    FILE* f = F.f;
+    if (fseek(f, 0, SEEK_END) != 0) return fail("write_index: seek failed for %s", path);
+    const int64_t chunk = std::max<int64_t>(1, ((size_t)64 << 20) / ((size_t)R.d * 4));
+    std::vector<int64_t> ids((size_t)std::min<int64_t>(chunk, R.nrows - have));
+    std::vector<float> buf(ids.size() * (size_t)R.d);
+    for (int64_t done = have; done < R.nrows; done += chunk) {
+        const int64_t cnt = std::min<int64_t>(chunk, R.nrows - done);
+        std::iota(ids.begin(), ids.begin() + cnt, done);
+        CHECK(read_rows(h, R, R.nrows, ids.data(), cnt, buf.data()));
+        if (!wr(f, buf.data(), (size_t)cnt * R.d * 4)) return fail("write_index: write failed");
+    }
+    // rows first, counts last: a crash in between leaves the old, still valid index with a longer tail
+    if (fflush(f) != 0) return fail("write_index: flush failed for %s", path);
+    if (fseek(f, 4 + 4, SEEK_SET) != 0 || !wr1<int64_t>(f, (int64_t)R.nrows) || fseek(f, kHeader, SEEK_SET) != 0 ||
+        !wr1<uint64_t>(f, (uint64_t)R.nrows * (uint64_t)R.d) || fflush(f) != 0)
+        return fail("write_index: header update failed for %s", path);
+    return 0;
+}
+
 // reads "IxFI" + header + payload into an existing empty flat-like store via store_add
 static int read_flat_into(ssmi_index* h, RowStore& R, FILE* f, int expect_d, int64_t* nread) {
     char cc[4];

@@ -324,9 +324,11 @@ class IndexIVFFlat(_IndexBase):
         return out
 
 
-def write_index(index: _IndexBase, path) -> None:
-    """Stand-in for faiss.write_index (core/index_manager.py:241)."""
-    _lib.check(index._lib.ssmi_index_write(index._handle(), os.fsencode(str(path))))
+def write_index(index: _IndexBase, path, incremental: bool = False) -> None:
+    """Stand-in for faiss.write_index (core/index_manager.py:241).  incremental=True: if `path` already holds an
+    earlier state of this Flat index, only the rows added since are appended (same bytes as a full write)."""
+    fn = index._lib.ssmi_index_write_append if incremental else index._lib.ssmi_index_write
+    _lib.check(fn(index._handle(), os.fsencode(str(path))))
 
 
 def read_index(path, storage: Optional[str] = None, device: Optional[int] = None) -> _IndexBase:

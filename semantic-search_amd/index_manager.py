@@ -236,7 +236,8 @@ class SemanticIndex:
     def save(self) -> None:
         """:238-242"""
         with self._lock:
-            faiss.write_index(self._faiss_index, str(self.faiss_path))
+            # a Flat index that only grew since the last checkpoint appends its new rows (same file, O(new rows))
+            faiss.write_index(self._faiss_index, str(self.faiss_path), incremental=True)
             self._save_config()
             if self._training_buffer_size:
                 np.save(self.training_buffer_path, np.vstack(self._training_buffer))

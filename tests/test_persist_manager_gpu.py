@@ -170,3 +170,38 @@ def test_training_buffer_survives_save_and_reload(ssa, tmp_path):
     si2.save()
     assert not si2.training_buffer_path.exists()
     si2.close()
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_incremental_write_is_byte_identical_to_full_write(ssa, tmp_path, storage):
+    """Checkpoints of a growing Flat index append the new rows; the file must equal a full rewrite at every step,
+    and a file that is not an earlier state of the index (another index, a truncated file) must be rewritten."""
+    d = 72
+    X = unit_rows(700, d, 3)
+    ix = ssa.IndexFlatIP(d, storage=storage)
+    inc, full = tmp_path / "inc.faiss", tmp_path / "full.faiss"
+    done = 0
+    for step in (300, 1, 0, 250, 149):
+        ix.add(X[done:done + step]); done += step
+        ssa.write_index(ix, inc, incremental=True)
+        ssa.write_index(ix, full)
+        assert inc.read_bytes() == full.read_bytes(), f"after {done} rows"
+    back = ssa.read_index(inc, storage=storage)
+    assert back.ntotal == 700
+    np.testing.assert_array_equal(back.reconstruct_n(0, 700), ix.reconstruct_n(0, 700))
+    # another index's file of the same shape: the last-row check forces a full rewrite
+    other = ssa.IndexFlatIP(d, storage=storage)
+    other.add(unit_rows(100, d, 4))
+    ssa.write_index(other, inc)
+    ssa.write_index(ix, inc, incremental=True)
+    assert inc.read_bytes() == full.read_bytes()
+    # a truncated file
+    inc.write_bytes(full.read_bytes()[:-10])
+    ssa.write_index(ix, inc, incremental=True)
+    assert inc.read_bytes() == full.read_bytes()
+    # an IVF index takes the full-write path
+    ivf = ssa.IndexIVFFlat(ssa.IndexFlatIP(d), d, 4, ssa.METRIC_INNER_PRODUCT)
+    ivf.set_centroids(unit_rows(4, d, 5)); ivf.add(X[:50])
+    a, b = tmp_path / "a.faiss", tmp_path / "b.faiss"
+    ssa.write_index(ivf, a, incremental=True); ssa.write_index(ivf, b)
+    assert a.read_bytes() == b.read_bytes()
