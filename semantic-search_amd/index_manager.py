@@ -304,22 +304,31 @@ class SemanticIndex:
             out.append(SearchResult(rec[0], rec[1], float(score), int(vid), rec[2] or "image"))
         return SearchResults(out, query_type, "")
 
-    def search(self, query_vector: np.ndarray, top_k: int = DEFAULT_TOP_K) -> SearchResults:
-        """:348-398"""
+    @staticmethod
+    def _apply_min_score(scores: np.ndarray, indices: np.ndarray, min_score: float):
+        """The search nodes' score filter (nodes/search_nodes.py:152-159: keep r.score >= min_score when
+        min_score > 0), applied to the engine's sorted result row before any metadata is looked up."""
+        if min_score is None or min_score <= 0.0:
+            return scores, indices
+        keep = int(np.searchsorted(-scores, -np.float32(min_score), side="right"))  # scores are sorted descending
+        return scores[:keep], indices[:keep]
+
+    def search(self, query_vector: np.ndarray, top_k: int = DEFAULT_TOP_K, min_score: float = 0.0) -> SearchResults:
+        """:348-398 (min_score is additive: SURVEY.md 8f rank 3)"""
         q = np.asarray(query_vector)
         if q.ndim == 1:
             q = q.reshape(1, -1)
         q = np.ascontiguousarray(q.astype(np.float32))
         with self._lock:
             scores, indices = self._faiss_index.search(q, top_k)
-        return self._results_from(scores[0], indices[0], "vector")
+        return self._results_from(*self._apply_min_score(scores[0], indices[0], min_score), "vector")
 
-    def search_batch(self, query_vectors: np.ndarray, top_k: int = DEFAULT_TOP_K) -> List[SearchResults]:
+    def search_batch(self, query_vectors: np.ndarray, top_k: int = DEFAULT_TOP_K, min_score: float = 0.0) -> List[SearchResults]:
         """Additive: every row of a (B, d) query matrix, one engine call (MFMA path for large B)."""
         q = np.ascontiguousarray(np.atleast_2d(np.asarray(query_vectors)).astype(np.float32))
         with self._lock:
             scores, indices = self._faiss_index.search(q, top_k)
-        return [self._results_from(s, i, "vector") for s, i in zip(scores, indices)]
+        return [self._results_from(*self._apply_min_score(s, i, min_score), "vector") for s, i in zip(scores, indices)]
 
     def search_with_exclusion(self, query_vector: np.ndarray, negative_vectors: List[np.ndarray], top_k: int = DEFAULT_TOP_K,
                               exclusion_threshold: float = 0.3) -> SearchResults:

@@ -121,6 +121,13 @@ def test_semantic_index_lifecycle(ssa, tmp_path):
     assert res[0].vector_id == 17 and res[0].file_path == "/img/17.jpg" and abs(res[0].score - 1.0) < 1e-5
     batch = si.search_batch(X[[3, 900]], top_k=3)
     assert [r[0].vector_id for r in batch] == [3, 900]
+    # the nodes' min_score filter (nodes/search_nodes.py:152-159), applied on the engine's sorted rows
+    full = si.search(X[17], top_k=50)
+    cut = float(full[9].score)
+    some = si.search(X[17], top_k=50, min_score=cut)
+    assert [r.vector_id for r in some] == [r.vector_id for r in full if r.score >= cut] and 10 <= len(some) < 50
+    assert len(si.search(X[17], top_k=50, min_score=2.0)) == 0
+    assert [len(r) for r in si.search_batch(X[[3, 900]], top_k=5, min_score=0.999)] == [1, 1]
     stats = si.get_stats()
     assert stats["vector_count"] == 1200 and stats["index_type"] == "ivf_flat" and stats["index_params"]["nlist"] == 100
     si.save()
