@@ -459,6 +459,20 @@ _index_cache: Dict[str, SemanticIndex] = {}     # :1481-1482
 _index_lock = threading.Lock()
 
 
+def search_multi_index(indexes: List["SemanticIndex"], query_vector: np.ndarray, top_k: int = DEFAULT_TOP_K,
+                       normalize_scores: bool = True, min_score: float = 0.0) -> SearchResults:
+    """Vector-level form of the SearchMultiIndex node (nodes/search_nodes.py:840-900): ONE encoded query searched in
+    every index with max(top_k, 50) candidates each (:868), merged by SemanticIndex.merge_search_results (:882-886),
+    then the min_score filter (:891-898).  The node re-encodes the text once per index (:871-878); here the caller
+    encodes once and passes the vector."""
+    per_index_k = max(top_k, 50)
+    merged = SemanticIndex.merge_search_results([ix.search(query_vector, per_index_k) for ix in indexes if ix is not None],
+                                                top_k=top_k, normalize_scores=normalize_scores)
+    if min_score > 0.0:
+        merged = SearchResults([r for r in merged.results if r.score >= min_score], merged.query_type, merged.query_info)
+    return merged
+
+
 def get_or_create_index(index_name: str, embedding_dim: int = 4096, index_type: str = "flat", **kwargs) -> SemanticIndex:
     """:1485-1504"""
     with _index_lock:

@@ -212,3 +212,20 @@ def test_incremental_write_is_byte_identical_to_full_write(ssa, tmp_path, storag
     a, b = tmp_path / "a.faiss", tmp_path / "b.faiss"
     ssa.write_index(ivf, a, incremental=True); ssa.write_index(ivf, b)
     assert a.read_bytes() == b.read_bytes()
+
+
+def test_search_multi_index_merges_like_the_node(ssa, tmp_path):
+    from semantic_search_amd.index_manager import SemanticIndex, search_multi_index
+    d = 64
+    X = unit_rows(600, d, 21)
+    a = SemanticIndex("a", embedding_dim=d, base_path=tmp_path)
+    b = SemanticIndex("b", embedding_dim=d, base_path=tmp_path)
+    a.add_vectors(X[:300], [f"/a/{i}.jpg" for i in range(300)], [f"/ta/{i}.jpg" for i in range(300)], [(1.0, 1)] * 300)
+    b.add_vectors(X[300:], [f"/b/{i}.jpg" for i in range(300)], [f"/tb/{i}.jpg" for i in range(300)], [(1.0, 1)] * 300)
+    q = X[310]
+    merged = search_multi_index([a, b, None], q, top_k=5, normalize_scores=False)
+    want = SemanticIndex.merge_search_results([a.search(q, 50), b.search(q, 50)], top_k=5, normalize_scores=False)
+    assert [(r.file_path, r.score) for r in merged] == [(r.file_path, r.score) for r in want]
+    assert merged[0].file_path == "/b/10.jpg"
+    assert len(search_multi_index([a, b], q, top_k=5, normalize_scores=False, min_score=0.99)) == 1
+    a.close(); b.close()
