@@ -997,6 +997,21 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
                     const double us = (double)(d[w * 4 + i] - t0) * 0.01;
                     sum[i] += us; mx[i] = std::max(mx[i], us); mn[i] = std::min(mn[i], us);
                 }
+            {   // is the spread of the finish times inside the blocks or between them?
+                const int nwb = qthreads / 64;
+                double within = 0, bmin = 1e30, bmax = 0;
+                for (int b = 0; b < gx; ++b) {
+                    double lo = 1e30, hi = 0, sum2 = 0;
+                    for (int w = 0; w < nwb; ++w) {
+                        const double us = (double)(d[((size_t)b * nwb + w) * 4 + 2] - t0) * 0.01;
+                        lo = std::min(lo, us); hi = std::max(hi, us); sum2 += us;
+                    }
+                    within += hi - lo;
+                    bmin = std::min(bmin, sum2 / nwb); bmax = std::max(bmax, sum2 / nwb);
+                }
+                fprintf(stderr, "[ivf stamp] rows-done spread: inside a block %.1f us on average; block means from %.1f to %.1f us\n",
+                        within / gx, bmin, bmax);
+            }
             fprintf(stderr, "[ivf stamp] us since first wave start (min/mean/max over %zu waves): start %.1f/%.1f/%.1f  first row load %.1f/%.1f/%.1f  "
                             "rows done %.1f/%.1f/%.1f  list published %.1f/%.1f/%.1f  merged %.1f\n", nwv,
                     mn[0], sum[0] / nwv, mx[0], mn[1], sum[1] / nwv, mx[1], mn[2], sum[2] / nwv, mx[2], mn[3], sum[3] / nwv, mx[3],
