@@ -101,8 +101,15 @@ __device__ __forceinline__ void merge_partials(const skey_t* lists, int P, int k
         skey_t* surv = lds + 2;                                       // [2, 2 + cap)
         const int nthreads = nwaves * 64;
         const int tid = wave * 64 + lane;
-        // own share of the keys: four loads in flight per thread and round
+        // own share of the keys: four loads in flight per thread and round; the first round is issued BEFORE the
+        // bound is known (wave 0 sorts the heads meanwhile), so the merge costs one memory round trip, not two
         if (tid == 0) *count_l = 0;
+        skey_t key[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + j * nthreads;
+            key[j] = (e < total) ? load_key<COHERENT>(lists + e) : 0;
+        }
         skey_t bound = 0;
         if (wave == 0) {
             WaveTopK<1> hd;
@@ -114,19 +121,20 @@ __device__ __forceinline__ void merge_partials(const skey_t* lists, int P, int k
         }
         __syncthreads();
         bound = *bound_l;
-        for (int base = tid; base < total; base += 4 * nthreads) {
-            skey_t key[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int e = base + j * nthreads;
-                key[j] = (e < total) ? load_key<COHERENT>(lists + e) : 0;
-            }
+        for (int base = tid;;) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (key[j] != 0 && key[j] >= bound) {
                     const unsigned pos = atomicAdd(count_l, 1u);
                     if (pos < (unsigned)kMergeSurvivorCap) surv[pos] = key[j];
                 }
+            }
+            base += 4 * nthreads;
+            if (base >= total) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = base + j * nthreads;
+                key[j] = (e < total) ? load_key<COHERENT>(lists + e) : 0;
             }
         }
         __syncthreads();
