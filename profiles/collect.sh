@@ -7,7 +7,7 @@ set -e
 TAG=${1:-r01}
 export TMPDIR=/tmp
 OUT=gpurun_out
-BENCH="python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-ivf-extra"  # the IVF side measurement launches the same scan kernel over the centroids: it would dilute the per-kernel averages
 MFMA="python3 tools/prof_mfma.py 1000000 4096 4096 10"
 IVF="python3 tools/prof_ivf.py 2000000 4096 1024 16"
 
