@@ -739,6 +739,15 @@ static int ivf_append_preassigned(ssmi_index* h, int64_t n, const float* xdev, c
         hipLaunchKernelGGL((scatter_rows_kernel<__half>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)h->ws[9],
                            (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, (uint32_t)h->ivf_ntotal, ids_dev, src_idx_dev);
     HIPCHECK(hipGetLastError());
+    if (h->has_shadow && R.dtype == SSMI_F32) {
+        // the fp16 shadow of the slot store (built by the first batched search, see ivf_search) follows every add
+        RowStore& H = h->shadow16;
+        CHECK(H.reserve(R.nrows, h->stream));
+        hipLaunchKernelGGL((scatter_rows_kernel<__half>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)h->ws[9],
+                           (void* const*)H.d_segs, H.seg_shift, S->d_slot_ids, (uint32_t)h->ivf_ntotal, ids_dev, src_idx_dev);
+        HIPCHECK(hipGetLastError());
+        H.nrows = R.nrows;
+    }
     HIPCHECK(hipStreamSynchronize(h->stream));
     h->ivf_ntotal += n;
     S->csr_dirty = true;
@@ -875,7 +884,19 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
     if (env_lm) list_major = env_lm[0] == '1';
     list_major = list_major && plan_ivf_list_scan(R.dtype, R.ld, k, &lbt, &lthreads, &llds);
     const char* env_lmm = getenv("SSMI_IVF_LIST_MFMA");  // 0: keep the register-FMA form
-    const bool list_mfma = list_major && ivf_list_mfma_supported(R.dtype, R.ld, k) && !(env_lmm && env_lmm[0] == '0');
+    // fp32 lists run the matrix-core scan on an fp16 shadow of the slot store (same policy as Flat: batches on
+    // fp32 storage trade exact fp32 products for the MFMA path; +50 % HBM; SSMI_NO_SHADOW=1 keeps them exact)
+    const bool via_shadow = list_major && R.dtype == SSMI_F32 && !getenv("SSMI_NO_SHADOW") &&
+                            ivf_list_mfma_supported(SSMI_F16, R.ld, k) && !(env_lmm && env_lmm[0] == '0');
+    const bool list_mfma = via_shadow || (list_major && ivf_list_mfma_supported(R.dtype, R.ld, k) && !(env_lmm && env_lmm[0] == '0'));
+    if (via_shadow && !h->has_shadow) {
+        CHECK(h->shadow16.init(R.d, SSMI_F16));
+        h->has_shadow = true;
+        CHECK(h->shadow16.reserve(R.nrows, s));
+        RowView src = R.view();
+        HIPCHECK(launch_shadow_rows(src, (void* const*)h->shadow16.d_segs, h->shadow16.seg_shift, 0, R.nrows, s));
+        h->shadow16.nrows = R.nrows;
+    }
     const size_t per_q = list_major ? (size_t)nprobe * k * sizeof(skey_t) : (size_t)gx * k * sizeof(skey_t);
     const int64_t qbatch = std::max<int64_t>(1, std::min<int64_t>(nq, ((size_t)256 << 20) / per_q));
     for (int64_t done = 0; done < nq; done += qbatch) {
@@ -901,6 +922,7 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
             if (list_mfma) {
                 // matrix-core form: up to 128 queries per list pass, queries rounded to fp16
                 A.bt = ivf_list_mfma_bt(nb, nprobe, h->nlist); A.threads = 512; A.lds = 0; A.max_units = 0;
+                if (via_shadow) A.X = h->shadow16.view();
                 CHECK(ensure_ws(h, 4, (size_t)nb * R.ld * 2));
                 CHECK(ensure_ws(h, 5, ivf_list_mfma_cand_bytes(h->num_cu)));
                 HIPCHECK(launch_cvt_queries_f16(qb, nb, nb, R.ld, h->ws[4], s));

@@ -78,8 +78,15 @@ def test_large_query_batch_uses_mfma_coarse_quantizer(ssa):
     assert agree > 0.97, agree
     index.nprobe = nlist
     D, I = index.search(Q, 10)
+    # every list probed by every query: the list-major matrix-core scan, which over fp32 lists reads their fp16
+    # shadow with fp16-rounded queries (exact against the oracle on the rounded operands) ...
+    assert index.last_timing()["last_grid"] < 0
+    Dr, Ir = flat_ip.search(r16(X), r16(Q), 10)
+    ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, r16(X), r16(Q), rtol=1e-5, tie_rtol=1e-5)
+    assert ok, msg
+    # ... and inside the north-star tolerance against the fp32 operands
     Dr, Ir = flat_ip.search(X, Q, 10)
-    ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, X, Q, rtol=1e-5, tie_rtol=1e-5)
+    ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, X, Q, rtol=1e-3, tie_rtol=1e-3, atol=1e-4)
     assert ok, msg
 
 
@@ -179,11 +186,14 @@ def test_list_sharded_ivf_equals_unsharded(ssa):
     (5000, 1024, 64, "f16", 130, "1"),    # matrix-core form: 16 queries per list pass (130*nprobe/64 probes per list)
     (9000, 512, 8, "f16", 200, "1"),      # ... 64 / 128 queries per list pass, lists of > 1000 rows, ragged last pages
     (3000, 4096, 6, "f16", 33, "1"),
+    (3000, 4096, 16, "f32", 20, "1"),     # fp32 lists: the matrix-core form runs on the fp16 shadow of the slot store
+    (5000, 1024, 64, "f32", 130, "1"),
 ])
 def test_list_major_batched_scan_matches_oracle_and_per_query_scan(ssa, monkeypatch, n, d, nlist, storage, nq, list_mfma):
     """K8b (ivf_lists.hip) and K8m (ivf_lists_mfma.hip): the list-major scan of a query batch must give what the
     per-query scan gives, and both must match the oracle fed with the index's own list assignment.  The
-    register-FMA form is exact in fp32; the matrix-core form rounds the queries to fp16 (north-star tolerance)."""
+    register-FMA form is exact in fp32; the matrix-core form rounds the queries to fp16 (north-star tolerance) and,
+    over fp32 lists, reads an fp16 shadow copy of the rows."""
     monkeypatch.setenv("SSMI_IVF_LIST_MFMA", list_mfma)
     X = clustered_rows(n, d, nlist, 71)
     C = clustered_rows(nlist, d, nlist, 72)
@@ -211,14 +221,16 @@ def test_list_major_batched_scan_matches_oracle_and_per_query_scan(ssa, monkeypa
                 # the north star's 1e-3 relative bound needs an absolute floor for scores near zero
                 ok, msg, _ = flat_ip.check_against(D, I, D2, I2, Xs, Q, rtol=1e-3, tie_rtol=1e-3, atol=1e-4)
                 assert ok, f"nprobe={nprobe} k={k} vs per-query scan: {msg}"
-                Dr, Ir, _ = ivf_flat.search(Xs, C, labels, r16(Q), k, nprobe, **coarse)
+                Xs_m = r16(X)  # rows as the matrix cores see them (the shadow of fp32 lists is rounded like fp16 storage)
+                Dr, Ir, _ = ivf_flat.search(Xs_m, C, labels, r16(Q), k, nprobe, **coarse)
             else:
                 np.testing.assert_array_equal(I, I2)
                 np.testing.assert_array_equal(D, D2)
                 Dr, Ir, _ = ivf_flat.search(Xs, C, labels, Q, k, nprobe, **coarse)
             Qs = r16(Q) if mfma else Q
+            Xc = r16(X) if mfma else Xs
             if nprobe == nlist or not coarse:
-                ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xs, Qs, rtol=1e-5, tie_rtol=1e-5)
+                ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xc, Qs, rtol=1e-5, tie_rtol=1e-5)
                 assert ok, f"nprobe={nprobe} k={k}: {msg}"
             else:  # fp16 coarse scores may swap two near-tied centroids at the probe boundary
                 agree = np.mean([len(set(a[a >= 0]) & set(b[b >= 0])) / max(1, (b >= 0).sum()) for a, b in zip(I, Ir)])
@@ -277,4 +289,25 @@ def test_many_probes_and_both_merge_forms(ssa, monkeypatch, no_tail):
             Dr, Ir, _ = ivf_flat.search(X, C, labels, Q, k, nprobe)
             ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, X, Q, rtol=1e-5, tie_rtol=1e-5)
             assert ok, f"nq={nq} nprobe={nprobe} k={k}: {msg}"
+    index.close()
+
+
+def test_fp32_lists_shadow_follows_adds(ssa):
+    """The fp16 shadow of an fp32 slot store is built by the first batched search and must then follow every add
+    (rows appended into half-filled pages included): a batched search after more adds sees all rows."""
+    d, nlist = 512, 16
+    X, C = clustered_rows(4000, d, nlist, 81), clustered_rows(nlist, d, nlist, 82)
+    index = make_ivf(ssa, d, nlist, "f32")
+    index.set_centroids(C)
+    index.add(X[:1500])
+    Q = X[np.arange(0, 4000, 100)]          # 40 queries: rows of the index-to-be
+    index.nprobe = nlist
+    D, I = index.search(Q, 1)
+    assert index.last_timing()["last_grid"] < 0          # list-major (matrix-core) path, shadow created
+    assert (I[:15, 0] == np.arange(0, 1500, 100)).all()
+    for s in range(1500, 4000, 37):                      # ragged adds into partially filled pages
+        index.add(X[s:s + 37])
+    D, I = index.search(Q, 1)
+    assert index.last_timing()["last_grid"] < 0
+    assert (I[:, 0] == np.arange(0, 4000, 100)).all() and (D[:, 0] > 0.999).all()
     index.close()

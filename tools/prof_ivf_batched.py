@@ -13,7 +13,8 @@ centres = torch.randn((ncl, d), generator=g, device=dev); centres /= centres.nor
 def rows(m):
     x = torch.randn((m, d), generator=g, device=dev) * (0.6 / d ** 0.5) + centres[torch.randint(0, ncl, (m,), generator=g, device=dev)]
     return x / x.norm(dim=1, keepdim=True)
-ivf = ssa.IndexIVFFlat(ssa.IndexFlatIP(d, storage="f16"), d, nlist, ssa.METRIC_INNER_PRODUCT, storage="f16")
+ST = os.environ.get("PROF_STORAGE", "f16")
+ivf = ssa.IndexIVFFlat(ssa.IndexFlatIP(d, storage=ST), d, nlist, ssa.METRIC_INNER_PRODUCT, storage=ST)
 ivf.train(rows(min(n, 64 * nlist)))
 for s in range(0, n, 65536):
     ivf.add(rows(min(65536, n - s)))
@@ -29,6 +30,6 @@ for B in batches:
     _, Ic = cq.search(Q, nprobe)
     probes = np.bincount(Ic.cpu().numpy().ravel(), minlength=nlist)
     passes = -(-probes // bt)
-    byts = float((sizes * passes).sum()) * d * 2
+    byts = float((sizes * passes).sum()) * d * 2  # fp16 bytes (fp32 lists are scanned through their fp16 shadow)
     print(f"B={B} group={bt}: wall {wall*1e3:.2f} ms ({B/wall:.0f} QPS), scan kernel {t['last_scan_ms']:.2f} ms, merge {t['last_merge_ms']:.3f} ms, "
           f"streams {byts/1e9:.1f} GB (union of probed lists {float(sizes[probes>0].sum())*d*2/1e9:.1f} GB) -> {byts/t['last_scan_ms']/1e9:.2f} TB/s in the scan kernel")
