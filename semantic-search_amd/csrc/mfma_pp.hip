@@ -27,6 +27,7 @@
 #ifdef SSMI_STAMP
 #include <cstdio>
 #include <vector>
+#include <algorithm>
 #endif
 
 namespace ssmi {
@@ -248,6 +249,15 @@ hipError_t launch_flat_mfma_pp(const MfmaParams& P_in, int r, int grid, size_t l
         std::vector<unsigned long long> h((size_t)grid * 48);
         (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
         const char* names[6] = {"wait", "loop", "prefetch", "filter", "sync", "compact"};
+        {   // how evenly do the workgroups finish?  (sum of all stamped segments of wave 0 per workgroup)
+            double mn = 1e30, mx = 0, sum = 0;
+            for (int b = 0; b < grid; ++b) {
+                double t = 0;
+                for (int i = 0; i < 6; ++i) t += (double)h[((size_t)b * 8) * 6 + i];
+                mn = std::min(mn, t); mx = std::max(mx, t); sum += t;
+            }
+            fprintf(stderr, "[stamp] workgroup totals (cycles): min %.0f mean %.0f max %.0f\n", mn, sum / grid, mx);
+        }
         for (int w : {0, 4}) {
             fprintf(stderr, "[stamp] wave %d:", w);
             for (int i = 0; i < 6; ++i) {
