@@ -28,6 +28,7 @@
 #include "scan_impl.h"
 
 #include "ivf_lists.h"
+#include "ivf_state.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -38,30 +39,6 @@ using namespace ssmi;
 
 namespace ssmi {
 
-static const int kPageRows = 32;
-static const int kPageShift = 5;
-
-struct IvfState {
-    RowStore cent32, cent16;
-    std::vector<std::vector<int>> pages;  // per list: page numbers in order
-    std::vector<long long> size;          // per list: vectors stored
-    long long npages = 0;
-    uint32_t* d_slot_ids = nullptr;
-    long long slot_cap = 0;
-    int* d_page_off = nullptr;  // nlist + 1
-    int* d_size = nullptr;      // nlist
-    int* d_pages = nullptr;     // npages (CSR payload)
-    long long d_pages_cap = 0;
-    bool csr_dirty = true;
-    bool has_direct_map = false;
-    std::vector<int64_t> direct_map;  // id -> slot
-    int niter = 10;                   // [FAISS-lib] ClusteringParameters default for the IVF quantizer
-    int max_points_per_centroid = 256;
-    uint64_t seed = 1234;
-};
-
-static IvfState* st(ssmi_index* h) { return reinterpret_cast<IvfState*>(h->ivf); }
-static const IvfState* st(const ssmi_index* h) { return reinterpret_cast<const IvfState*>(h->ivf); }
 
 // ---------------------------------------------------------------------------
 // kernels
@@ -495,7 +472,7 @@ void ivf_destroy(ssmi_index* h) {
 }
 
 // (n,d) rows of src_dtype, host or device -> (n, ld) fp32 on the device (workspace slot 8 when a copy is needed)
-static int rows_to_device_f32(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind, const float** out) {
+int rows_to_device_f32(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind, const float** out) {
     const RowStore& R = h->rows;
     if (mem_kind == SSMI_DEVICE && src_dtype == SSMI_F32 && R.ld == R.d) { *out = (const float*)x; return 0; }
     CHECK(ensure_ws(h, 8, (size_t)n * R.ld * 4));
@@ -539,7 +516,7 @@ static int assign_to_centroids(ssmi_index* h, int64_t n, const float* xdev, std:
     return 0;
 }
 
-static int install_centroids(ssmi_index* h, const float* c, int mem_kind) {
+int install_centroids(ssmi_index* h, const float* c, int mem_kind) {
     IvfState* S = st(h);
     S->cent32.nrows = 0;
     S->cent16.nrows = 0;
@@ -703,8 +680,8 @@ static int ensure_slots(ssmi_index* h, long long npages) {
 }
 
 // append vectors (on the device as (n, ld) fp32) to given lists; ids == nullptr: sequential ids from ntotal
-static int ivf_append_preassigned(ssmi_index* h, int64_t n, const float* xdev, const int* labels, const uint32_t* ids_host,
-                                  const int* src_idx_host = nullptr) {
+int ivf_append_preassigned(ssmi_index* h, int64_t n, const float* xdev, const int* labels, const uint32_t* ids_host,
+                           const int* src_idx_host) {
     if (n == 0) return 0;
     IvfState* S = st(h);
     std::vector<int> dst((size_t)n);
@@ -1162,303 +1139,6 @@ int ssmi_index_get_assignments(const ssmi_index* hc, int32_t* out_host) {
             if (id >= (uint32_t)h->ivf_ntotal) return fail("internal: slot %lld holds id %u", slot, id);
             out_host[id] = l;
         }
-    return 0;
-}
-
-// ---------------------------------------------------------------------------
-// persistence: FAISS index-file layout (faiss/impl/index_write.cpp [FAISS-lib],
-// restated from the published format; not yet validated against a FAISS-written
-// file because none exists in this environment):
-//   IndexFlatIP   "IxFI" | header | n_floats:u64 | n_floats * f32
-//   IndexIVFFlat  "IwFl" | header | nlist:u64 | nprobe:u64 | quantizer index ("IxFI"...) |
-//                 direct map (type:u8, array: u64 n + n * i64) |
-//                 "ilar" | nlist:u64 | code_size:u64 | "full" | sizes: u64 n + n * u64 |
-//                 per non-empty list: codes (size * code_size bytes) then ids (size * i64)
-//   header        d:i32 | ntotal:i64 | 1<<20:i64 | 1<<20:i64 | is_trained:u8 | metric_type:i32 (0 = inner product)
-// Vectors are written as fp32 whatever the storage type (an fp16-storage index
-// round-trips exactly: fp16 -> fp32 -> fp16 is lossless).
-// ---------------------------------------------------------------------------
-}  // extern "C" (reopened below)
-namespace {
-
-struct File {
-    FILE* f = nullptr;
-    ~File() { if (f) fclose(f); }
-};
-bool wr(FILE* f, const void* p, size_t n) { return n == 0 || fwrite(p, 1, n, f) == n; }
-bool rd(FILE* f, void* p, size_t n) { return n == 0 || fread(p, 1, n, f) == n; }
-template <typename T> bool wr1(FILE* f, T v) { return wr(f, &v, sizeof v); }
-template <typename T> bool rd1(FILE* f, T* v) { return rd(f, v, sizeof *v); }
-
-bool write_header(FILE* f, int d, int64_t ntotal, bool trained) {
-    const int64_t dummy = 1 << 20;
-    return wr1<int32_t>(f, d) && wr1<int64_t>(f, ntotal) && wr1<int64_t>(f, dummy) && wr1<int64_t>(f, dummy) &&
-           wr1<uint8_t>(f, trained ? 1 : 0) && wr1<int32_t>(f, 0);
-}
-int read_header(FILE* f, int* d, int64_t* ntotal, bool* trained) {
-    int32_t dd, metric; int64_t nt, d1, d2; uint8_t tr;
-    if (!(rd1(f, &dd) && rd1(f, &nt) && rd1(f, &d1) && rd1(f, &d2) && rd1(f, &tr) && rd1(f, &metric)))
-        return fail("read_index: truncated index header");
-    if (metric != 0) return fail("read_index: metric type %d is not supported (only METRIC_INNER_PRODUCT)", metric);
-    if (dd < 1 || nt < 0) return fail("read_index: corrupt header (d=%d ntotal=%lld)", dd, (long long)nt);
-    *d = dd; *ntotal = nt; *trained = tr != 0;
-    return 0;
-}
-
-// rows named by `slots` of a row store -> fp32 (n, d) on the host, through the gather kernel
-int read_rows(ssmi_index* h, const RowStore& R, long long view_rows, const int64_t* slots, int64_t n, float* out) {
-    const int64_t chunk = std::max<int64_t>(1, ((size_t)64 << 20) / ((size_t)R.d * 4));
-    for (int64_t done = 0; done < n; done += chunk) {
-        const int64_t cnt = std::min(chunk, n - done);
-        const size_t ids_bytes = ((size_t)cnt * 8 + 255) / 256 * 256;
-        CHECK(ensure_ws(h, 0, ids_bytes + 256 + (size_t)cnt * R.d * 4));
-        int64_t* dids = (int64_t*)h->ws[0];
-        int* bad = (int*)((char*)h->ws[0] + ids_bytes);
-        float* dout = (float*)((char*)h->ws[0] + ids_bytes + 256);
-        HIPCHECK(hipMemcpyAsync(dids, slots + done, (size_t)cnt * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(hipMemsetAsync(bad, 0, 4, h->stream));
-        RowView v = R.view();
-        v.nrows = view_rows;
-        HIPCHECK(launch_gather_rows(v, R.dtype, dids, cnt, R.d, dout, bad, h->stream));
-        HIPCHECK(hipMemcpyAsync(out + (size_t)done * R.d, dout, (size_t)cnt * R.d * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(hipStreamSynchronize(h->stream));
-    }
-    return 0;
-}
-
-int write_flat_payload(ssmi_index* h, const RowStore& R, long long nrows, FILE* f) {
-    if (!wr1<uint64_t>(f, (uint64_t)nrows * (uint64_t)R.d)) return fail("write_index: write failed");
-    const int64_t chunk = std::max<int64_t>(1, ((size_t)64 << 20) / ((size_t)R.d * 4));
-    std::vector<int64_t> ids((size_t)std::min<int64_t>(chunk, std::max<long long>(nrows, 1)));
-    std::vector<float> buf(ids.size() * (size_t)R.d);
-    for (int64_t done = 0; done < nrows; done += chunk) {
-        const int64_t cnt = std::min<int64_t>(chunk, nrows - done);
-        std::iota(ids.begin(), ids.begin() + cnt, done);
-        CHECK(read_rows(h, R, nrows, ids.data(), cnt, buf.data()));
-        if (!wr(f, buf.data(), (size_t)cnt * R.d * 4)) return fail("write_index: write failed");
-    }
-    return 0;
-}
-
-}  // namespace
-extern "C" {
-
-int ssmi_index_write(ssmi_index* h, const char* path) {
-    if (!h || !path) return fail("NULL argument");
-    DeviceGuard g(h->device);
-    File F;
-    F.f = fopen(path, "wb");
-    if (!F.f) return fail("write_index: cannot open %s for writing", path);
-    FILE* f = F.f;
-    const RowStore& R = h->rows;
-    if (h->kind == SSMI_KIND_FLAT) {
-        if (!wr(f, "IxFI", 4) || !write_header(f, R.d, R.nrows, true)) return fail("write_index: write failed");
-        CHECK(write_flat_payload(h, R, R.nrows, f));
-    } else {
-        IvfState* S = st(h);
-        if (!wr(f, "IwFl", 4) || !write_header(f, R.d, h->ivf_ntotal, h->trained)) return fail("write_index: write failed");
-        if (!wr1<uint64_t>(f, (uint64_t)h->nlist) || !wr1<uint64_t>(f, (uint64_t)h->nprobe)) return fail("write_index: write failed");
-        const long long ncent = h->trained ? h->nlist : 0;
-        if (!wr(f, "IxFI", 4) || !write_header(f, R.d, ncent, true)) return fail("write_index: write failed");
-        CHECK(write_flat_payload(h, S->cent32, ncent, f));
-        if (!wr1<uint8_t>(f, 0) || !wr1<uint64_t>(f, 0)) return fail("write_index: write failed");  // direct map: none
-        if (!wr(f, "ilar", 4) || !wr1<uint64_t>(f, (uint64_t)h->nlist) || !wr1<uint64_t>(f, (uint64_t)R.d * 4) ||
-            !wr(f, "full", 4) || !wr1<uint64_t>(f, (uint64_t)h->nlist))
-            return fail("write_index: write failed");
-        for (int l = 0; l < h->nlist; ++l)
-            if (!wr1<uint64_t>(f, (uint64_t)S->size[l])) return fail("write_index: write failed");
-        std::vector<uint32_t> sids((size_t)h->ivf_slots_used);
-        if (!sids.empty()) HIPCHECK(hipMemcpy(sids.data(), S->d_slot_ids, sids.size() * 4, hipMemcpyDeviceToHost));
-        std::vector<int64_t> slots, ids64;
-        std::vector<float> buf;
-        for (int l = 0; l < h->nlist; ++l) {
-            const long long n = S->size[l];
-            if (n == 0) continue;
-            slots.resize((size_t)n); ids64.resize((size_t)n); buf.resize((size_t)n * R.d);
-            for (long long pos = 0; pos < n; ++pos) {
-                slots[pos] = (long long)S->pages[l][pos >> kPageShift] * kPageRows + (pos & (kPageRows - 1));
-                ids64[pos] = (int64_t)sids[(size_t)slots[pos]];
-            }
-            CHECK(read_rows(h, R, h->ivf_slots_used, slots.data(), n, buf.data()));
-            if (!wr(f, buf.data(), (size_t)n * R.d * 4) || !wr(f, ids64.data(), (size_t)n * 8)) return fail("write_index: write failed");
-        }
-    }
-    if (fflush(f) != 0) return fail("write_index: flush failed for %s", path);
-    return 0;
-}
-
-// Checkpoint of a growing Flat index: when `path` already holds an earlier state of THIS index (same d, a
-// prefix of its rows - checked on the header, the file size and the last stored row), only the rows added since
-// are appended and the two counts in the header are patched; the result is byte-identical to ssmi_index_write.
-// Anything else (no file, another index, an IVF index) is a full rewrite.  The reference rewrites the whole file
-// at every checkpoint (core/index_manager.py:859-860 -> :241): N*d*4 bytes each time.
-int ssmi_index_write_append(ssmi_index* h, const char* path) {
-    if (!h || !path) return fail("NULL argument");
-    if (h->kind != SSMI_KIND_FLAT) return ssmi_index_write(h, path);
-    DeviceGuard g(h->device);
-    const RowStore& R = h->rows;
-    const long kHeader = 4 + 33;  // fourcc + header; then n_floats:u64, then the rows
-    int64_t have = -1;
-    {
-        File F;
-        F.f = fopen(path, "rb");
-        if (F.f) {
-            char cc[4];
-            int d = 0; int64_t nt = 0; bool tr = false; uint64_t nfl = 0;
-            if (rd(F.f, cc, 4) && memcmp(cc, "IxFI", 4) == 0 && read_header(F.f, &d, &nt, &tr) == 0 && rd1(F.f, &nfl) &&
-                d == R.d && nt <= R.nrows && nfl == (uint64_t)nt * (uint64_t)d && fseek(F.f, 0, SEEK_END) == 0 &&
-                (uint64_t)ftell(F.f) == (uint64_t)kHeader + 8 + nfl * 4) {
-                have = nt;
-                if (nt > 0) {  // the last stored row must be row nt-1 of this index
-                    std::vector<float> on_disk((size_t)d), ours((size_t)d);
-                    const int64_t id = nt - 1;
-                    if (fseek(F.f, kHeader + 8 + (long)((uint64_t)id * d * 4), SEEK_SET) != 0 || !rd(F.f, on_disk.data(), (size_t)d * 4)) have = -1;
-                    else {
-                        CHECK(read_rows(h, R, R.nrows, &id, 1, ours.data()));
-                        if (memcmp(on_disk.data(), ours.data(), (size_t)d * 4) != 0) have = -1;
-                    }
-                }
-            }
-        }
-    }
-    if (have < 0) return ssmi_index_write(h, path);
-    if (have == R.nrows) return 0;  // nothing new
-    File F;
-    F.f = fopen(path, "r+b");
-    if (!F.f) return ssmi_index_write(h, path);
-    FILE* f = F.f;
-    if (fseek(f, 0, SEEK_END) != 0) return fail("write_index: seek failed for %s", path);
-    const int64_t chunk = std::max<int64_t>(1, ((size_t)64 << 20) / ((size_t)R.d * 4));
-    std::vector<int64_t> ids((size_t)std::min<int64_t>(chunk, R.nrows - have));
-    std::vector<float> buf(ids.size() * (size_t)R.d);
-    for (int64_t done = have; done < R.nrows; done += chunk) {
-        const int64_t cnt = std::min<int64_t>(chunk, R.nrows - done);
-        std::iota(ids.begin(), ids.begin() + cnt, done);
-        CHECK(read_rows(h, R, R.nrows, ids.data(), cnt, buf.data()));
-        if (!wr(f, buf.data(), (size_t)cnt * R.d * 4)) return fail("write_index: write failed");
-    }
-    // rows first, counts last: a crash in between leaves the old, still valid index with a longer tail
-    if (fflush(f) != 0) return fail("write_index: flush failed for %s", path);
-    if (fseek(f, 4 + 4, SEEK_SET) != 0 || !wr1<int64_t>(f, (int64_t)R.nrows) || fseek(f, kHeader, SEEK_SET) != 0 ||
-        !wr1<uint64_t>(f, (uint64_t)R.nrows * (uint64_t)R.d) || fflush(f) != 0)
-        return fail("write_index: header update failed for %s", path);
-    return 0;
-}
-
-// reads "IxFI" + header + payload into an existing empty flat-like store via store_add
-static int read_flat_into(ssmi_index* h, RowStore& R, FILE* f, int expect_d, int64_t* nread) {
-    char cc[4];
-    if (!rd(f, cc, 4)) return fail("read_index: truncated file");
-    if (memcmp(cc, "IxFI", 4) != 0) return fail("read_index: unsupported index type '%.4s' (expected IxFI)", cc);
-    int d; int64_t nt; bool tr;
-    CHECK(read_header(f, &d, &nt, &tr));
-    if (expect_d > 0 && d != expect_d) return fail("read_index: nested index dimension %d != %d", d, expect_d);
-    uint64_t nfl;
-    if (!rd1(f, &nfl)) return fail("read_index: truncated file");
-    if (nfl != (uint64_t)nt * (uint64_t)d) return fail("read_index: payload size %llu != ntotal*d", (unsigned long long)nfl);
-    const int64_t chunk = std::max<int64_t>(1, ((size_t)64 << 20) / ((size_t)d * 4));
-    std::vector<float> buf((size_t)std::min<int64_t>(chunk, std::max<int64_t>(nt, 1)) * d);
-    for (int64_t done = 0; done < nt; done += chunk) {
-        const int64_t cnt = std::min(chunk, nt - done);
-        if (!rd(f, buf.data(), (size_t)cnt * d * 4)) return fail("read_index: truncated vector payload");
-        CHECK(store_add(h, R, cnt, buf.data(), SSMI_F32, SSMI_HOST));
-    }
-    *nread = nt;
-    return 0;
-}
-
-int ssmi_index_read(const char* path, int storage_dtype, int device, ssmi_index** out) {
-    if (!path || !out) return fail("NULL argument");
-    *out = nullptr;
-    if (storage_dtype < 0) storage_dtype = SSMI_F32;
-    File F;
-    F.f = fopen(path, "rb");
-    if (!F.f) return fail("read_index: cannot open %s", path);
-    FILE* f = F.f;
-    char cc[4];
-    if (!rd(f, cc, 4)) return fail("read_index: %s is empty", path);
-    if (memcmp(cc, "IxFI", 4) == 0) {
-        // peek the dimension, then let read_flat_into re-parse from the start
-        int32_t d;
-        if (!rd1(f, &d) || d < 1) return fail("read_index: corrupt header");
-        if (fseek(f, 0, SEEK_SET) != 0) return fail("read_index: seek failed");
-        ssmi_index* h = nullptr;
-        CHECK(ssmi_index_create_flat(d, storage_dtype, device, &h));
-        DeviceGuard g(device);
-        int64_t n;
-        if (read_flat_into(h, h->rows, f, d, &n)) { ssmi_index_free(h); return 1; }
-        *out = h;
-        return 0;
-    }
-    if (memcmp(cc, "IwFl", 4) != 0)
-        return fail("read_index: unsupported index type '%.4s' (this engine reads IxFI and IwFl)", cc);
-    int d; int64_t ntotal; bool trained;
-    CHECK(read_header(f, &d, &ntotal, &trained));
-    uint64_t nlist, nprobe;
-    if (!rd1(f, &nlist) || !rd1(f, &nprobe) || nlist < 1 || nlist > (1u << 24)) return fail("read_index: corrupt IVF header");
-    ssmi_index* h = nullptr;
-    CHECK(ssmi_index_create_ivfflat(d, (int)nlist, storage_dtype, device, &h));
-    struct Guard { ssmi_index* h; ~Guard() { if (h) ssmi_index_free(h); } } guard{h};
-    DeviceGuard g(device);
-    h->nprobe = (int)std::max<uint64_t>(1, nprobe);
-    IvfState* S = st(h);
-    int64_t ncent = 0;
-    S->cent32.nrows = 0;
-    CHECK(read_flat_into(h, S->cent32, f, d, &ncent));
-    if (ncent != 0 && ncent != (int64_t)nlist) return fail("read_index: quantizer holds %lld centroids, nlist is %llu", (long long)ncent, (unsigned long long)nlist);
-    if (ncent) {
-        std::vector<float> c((size_t)nlist * d);
-        h->trained = true;
-        CHECK(ssmi_index_get_centroids(h, c.data()));
-        CHECK(install_centroids(h, c.data(), SSMI_HOST));
-    }
-    h->trained = trained && ncent > 0;
-    uint8_t dm_type; uint64_t dm_n;
-    if (!rd1(f, &dm_type) || !rd1(f, &dm_n)) return fail("read_index: truncated direct map");
-    if (dm_type > 1) return fail("read_index: hashtable direct maps are not supported");
-    if (fseek(f, (long)(dm_n * 8), SEEK_CUR) != 0) return fail("read_index: seek failed");
-    uint64_t il_nlist, code_size, nsz;
-    if (!rd(f, cc, 4) || memcmp(cc, "ilar", 4) != 0) return fail("read_index: unsupported inverted-list type '%.4s'", cc);
-    if (!rd1(f, &il_nlist) || !rd1(f, &code_size) || il_nlist != nlist || code_size != (uint64_t)d * 4)
-        return fail("read_index: inverted lists do not match the index header");
-    if (!rd(f, cc, 4)) return fail("read_index: truncated file");
-    std::vector<uint64_t> sizes((size_t)nlist, 0);
-    if (memcmp(cc, "full", 4) == 0) {
-        if (!rd1(f, &nsz) || nsz != nlist || !rd(f, sizes.data(), (size_t)nlist * 8)) return fail("read_index: corrupt list sizes");
-    } else if (memcmp(cc, "sprs", 4) == 0) {
-        if (!rd1(f, &nsz) || (nsz & 1)) return fail("read_index: corrupt sparse list sizes");
-        std::vector<uint64_t> pairs((size_t)nsz);
-        if (!rd(f, pairs.data(), (size_t)nsz * 8)) return fail("read_index: corrupt sparse list sizes");
-        for (size_t i = 0; i + 1 < pairs.size(); i += 2) {
-            if (pairs[i] >= nlist) return fail("read_index: corrupt sparse list sizes");
-            sizes[(size_t)pairs[i]] = pairs[i + 1];
-        }
-    } else {
-        return fail("read_index: unknown list-size encoding '%.4s'", cc);
-    }
-    std::vector<float> buf; std::vector<int64_t> ids64; std::vector<uint32_t> ids32; std::vector<int> labels;
-    int64_t got = 0;
-    for (uint64_t l = 0; l < nlist; ++l) {
-        const int64_t n = (int64_t)sizes[(size_t)l];
-        if (n == 0) continue;
-        buf.resize((size_t)n * d); ids64.resize((size_t)n); ids32.resize((size_t)n); labels.assign((size_t)n, (int)l);
-        if (!rd(f, buf.data(), (size_t)n * d * 4) || !rd(f, ids64.data(), (size_t)n * 8)) return fail("read_index: truncated inverted list %llu", (unsigned long long)l);
-        for (int64_t i = 0; i < n; ++i) {
-            if (ids64[i] < 0 || ids64[i] >= 0xFFFFFFFFll) return fail("read_index: id %lld out of the supported range", (long long)ids64[i]);
-            ids32[i] = (uint32_t)ids64[i];
-        }
-        const int64_t chunk = std::max<int64_t>(1, ((size_t)256 << 20) / ((size_t)d * 4));
-        for (int64_t done = 0; done < n; done += chunk) {
-            const int64_t cnt = std::min(chunk, n - done);
-            const float* xdev = nullptr;
-            CHECK(rows_to_device_f32(h, cnt, buf.data() + (size_t)done * d, SSMI_F32, SSMI_HOST, &xdev));
-            CHECK(ivf_append_preassigned(h, cnt, xdev, labels.data() + done, ids32.data() + done));
-        }
-        got += n;
-    }
-    if (got != ntotal) return fail("read_index: lists hold %lld vectors, header says %lld", (long long)got, (long long)ntotal);
-    guard.h = nullptr;
-    *out = h;
     return 0;
 }
 

@@ -1,0 +1,40 @@
+// ivf_state.h - host-side state of an IVF-Flat index (internal to libssmi; shared by ivf.hip and persist.hip).
+#pragma once
+#include "index.h"
+#include <vector>
+
+namespace ssmi {
+
+static const int kPageRows = 32;
+static const int kPageShift = 5;
+
+struct IvfState {
+    RowStore cent32, cent16;
+    std::vector<std::vector<int>> pages;  // per list: page numbers in order
+    std::vector<long long> size;          // per list: vectors stored
+    long long npages = 0;
+    uint32_t* d_slot_ids = nullptr;
+    long long slot_cap = 0;
+    int* d_page_off = nullptr;  // nlist + 1
+    int* d_size = nullptr;      // nlist
+    int* d_pages = nullptr;     // npages (CSR payload)
+    long long d_pages_cap = 0;
+    bool csr_dirty = true;
+    bool has_direct_map = false;
+    std::vector<int64_t> direct_map;  // id -> slot
+    int niter = 10;                   // [FAISS-lib] ClusteringParameters default for the IVF quantizer
+    int max_points_per_centroid = 256;
+    uint64_t seed = 1234;
+};
+
+inline IvfState* st(ssmi_index* h) { return reinterpret_cast<IvfState*>(h->ivf); }
+inline const IvfState* st(const ssmi_index* h) { return reinterpret_cast<const IvfState*>(h->ivf); }
+
+// ivf.hip, used by the file reader (persist.hip)
+int rows_to_device_f32(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind, const float** out);
+int install_centroids(ssmi_index* h, const float* c, int mem_kind);
+// append vectors (on the device as (n, ld) fp32) to given lists; ids == nullptr: sequential ids from ntotal
+int ivf_append_preassigned(ssmi_index* h, int64_t n, const float* xdev, const int* labels, const uint32_t* ids_host,
+                           const int* src_idx_host = nullptr);
+
+}  // namespace ssmi
