@@ -16,13 +16,16 @@
 //               a host-side vector of page numbers (mirrored to the device as a
 //               CSR), so appending never moves existing vectors
 //   slot_ids    uint32 id of the vector in each slot
-// Search
-//   coarse top-nprobe (K1/K2 + K3)  ->  ivf_plan_kernel: per query, exclusive
-//   prefix sum of the probed lists' sizes  ->  ivf_scan_topk_kernel: the probed
-//   rows of a query form one virtual range [0, T) that is split evenly over all
-//   waves of the grid (row granular, so short and long lists balance); each wave
-//   maps its sub-range back to (list, page, slot) and runs the same
-//   coalesced-row / register-top-k loop as K1  ->  K3 merge.
+// Search (ivf_search)
+//   per-query form (batches whose probes do not revisit lists), two launches for a batch-1 search:
+//     coarse top-nprobe over the centroids (K1; its merge tail also writes the probe plan: exclusive prefix
+//     sums of the probed lists' sizes and their page-table offsets)  ->  ivf_scan_qreg_kernel: the probed rows
+//     of a query form one virtual range [0, T) split evenly over all waves of the grid (row granular, so short
+//     and long lists balance); query and probe plan in registers, K1's coalesced-row / register-top-k loop,
+//     merge tail (tail_merge.h).  ivf_scan_topk_kernel is the generic form for other row lengths.
+//   list-major form (batches that revisit lists): ivf_lists.hip (register FMA) / ivf_lists_mfma.hip (matrix
+//     cores; fp32 lists through an fp16 shadow of the slot store)  ->  K3 merges the nprobe lists of a query.
+// Persistence lives in persist.hip, the host-side state in ivf_state.h.
 #include "index.h"
 #include "kernels.h"
 #include "scan_impl.h"
