@@ -14,8 +14,10 @@
 // never leave the wave: after a 6-step butterfly the wave-uniform score is
 // compared with the wave's current k-th best and, rarely, inserted into the
 // register-resident sorted list (topk.h).  At the end the waves of a block
-// merge their lists through LDS and the block writes ONE k-entry list per
-// query; K3 (merge.hip) merges the per-block lists.
+// merge their lists through LDS and the block publishes ONE k-entry list per
+// query; the block that publishes the last list of a query tile merges them all
+// into (D, I) (tail_merge.h), so a batch-1 search is one launch.  Without a ticket
+// counter the lists are left to a K3 launch (merge.hip).
 #pragma once
 #include "common.h"
 #include "topk.h"
