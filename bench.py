@@ -201,7 +201,10 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU (MI355X)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SSMI_BENCH_FORCE_DIST=1: rehearse the multi-rank code path (process group, barriers, max over ranks, sharded
+    # search with its RCCL all-gather) on a single rank
+    dist_on = world > 1 or os.environ.get("SSMI_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         dist.init_process_group("nccl", device_id=dev)
 
     from semantic_search_amd.sharded import ShardedFlatIP, shard_bounds
@@ -211,6 +214,8 @@ def main():
     index = ShardedFlatIP(args.d, storage=args.storage, device=local_rank)
     index.add_local_random_unit(n_local, seed=1234 + rank)
     index.finalize(device=dev)
+    if dist_on and world == 1:
+        index._force_pipeline = True  # rehearsal: take the all-gather + merge path although there is one rank
 
     g = torch.Generator(device="cpu").manual_seed(4321)
     nsets = 8  # rotate over a few query batches so no step repeats the previous one
@@ -223,18 +228,18 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -282,16 +287,16 @@ def main():
             Qb = (Qb / Qb.norm(dim=-1, keepdim=True)).to(dev)
             index.search(Qb[0], args.k)
             torch.cuda.synchronize()
-            if world > 1:
+            if dist_on:
                 dist.barrier()
             t0 = time.perf_counter()
             for i in range(steps):
                 index.search(Qb[i % 2], args.k)
             torch.cuda.synchronize()
-            if world > 1:
+            if dist_on:
                 dist.barrier()
             el = time.perf_counter() - t0
-            if world > 1:
+            if dist_on:
                 t = torch.tensor([el], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 el = float(t.item())
@@ -386,7 +391,7 @@ def main():
             except Exception as e:
                 extra["flat_c3"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
