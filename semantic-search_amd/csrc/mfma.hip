@@ -28,15 +28,17 @@
 
 namespace ssmi {
 
-__global__ void cvt_queries_f16_kernel(const float* __restrict__ q, int nq, int ld, _Float16* __restrict__ out) {
+__global__ void cvt_queries_f16_kernel(const float* __restrict__ q, int nq, int ld, _Float16* __restrict__ out,
+                                       unsigned* __restrict__ gthr) {
     const int i = blockIdx.x;  // padded row
+    if (gthr && threadIdx.x == 0) gthr[i] = 0;
     for (int e = threadIdx.x; e < ld; e += blockDim.x)
         out[(size_t)i * ld + e] = (i < nq) ? (_Float16)q[(size_t)i * ld + e] : (_Float16)0.f;
 }
 
 // (nq, ld) fp32 -> (rows_out, ld) fp16, zero rows beyond nq
 hipError_t launch_cvt_queries_f16(const float* q, int nq, int rows_out, int ld, void* out, hipStream_t s) {
-    hipLaunchKernelGGL(cvt_queries_f16_kernel, dim3(rows_out), dim3(256), 0, s, q, nq, ld, (_Float16*)out);
+    hipLaunchKernelGGL(cvt_queries_f16_kernel, dim3(rows_out), dim3(256), 0, s, q, nq, ld, (_Float16*)out, (unsigned*)nullptr);
     return hipGetLastError();
 }
 
@@ -50,7 +52,7 @@ bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_c
     p->rows_per_slice = (row_tiles + ns - 1) / ns * TM;
     p->nslices = (int)((nrows + p->rows_per_slice - 1) / p->rows_per_slice);
     p->grid = p->nqt * p->nslices;
-    p->qh_bytes = (size_t)p->nqt * TN * ld * 2;
+    p->qh_bytes = (size_t)p->nqt * TN * ld * 2 + (size_t)p->nqt * TN * sizeof(unsigned);  // fp16 queries + shared thresholds
     p->cand_bytes = (size_t)p->grid * TN * CAND_CAP * sizeof(skey_t);
     const char* env_n = getenv("SSMI_MFMA_NARROW");
     p->narrow = nq <= N128_TN && !(env_n && env_n[0] == '0');
@@ -60,12 +62,15 @@ bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_c
 
 hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, const MfmaPlan& p, void* qh, void* cand,
                             skey_t* partial, hipStream_t s) {
-    hipLaunchKernelGGL(cvt_queries_f16_kernel, dim3(p.nqt * TN), dim3(256), 0, s, Q, nq, X.ld, (_Float16*)qh);
+    unsigned* gthr = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(qh) + (size_t)p.nqt * TN * X.ld * 2);
+    static const bool share_thr = !(getenv("SSMI_MFMA_SHARE_THR") && getenv("SSMI_MFMA_SHARE_THR")[0] == '0');
+    hipLaunchKernelGGL(cvt_queries_f16_kernel, dim3(p.nqt * TN), dim3(256), 0, s, Q, nq, X.ld, (_Float16*)qh, gthr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     MfmaParams P;
     P.X = X; P.Qh = (const _Float16*)qh; P.nq = nq; P.k = k; P.nqt = p.nqt; P.nslices = p.nslices;
     P.rows_per_slice = p.rows_per_slice; P.partial = partial; P.cand = (skey_t*)cand;
+    P.gthr = (share_thr && p.nslices > 1) ? gthr : nullptr;
     int r = 1;
     while (64 * r < k) r <<= 1;
     if (p.narrow) {

@@ -19,6 +19,8 @@ struct MfmaParams {
     long long rows_per_slice;  // multiple of 256
     skey_t* partial;           // [nq][nslices][k]
     skey_t* cand;              // [gridDim.x][256][CAND_CAP]
+    unsigned* gthr;            // [nqt*256] per query: highest k-th score any slice has reached (f32_to_ord bits,
+                               // 0 = none), zeroed by the query conversion; 256-query kernel only
 #ifdef SSMI_STAMP
     unsigned long long* dbg;   // diagnostic build only: per-wave cycle sums
 #endif
@@ -148,7 +150,7 @@ __device__ __forceinline__ float vmax2(float a, float b) {
 // the wave's row half, query n*16 + frow of its query quarter).  Per query column the 32 values
 // of a lane are first reduced to per-accumulator maxima and one column maximum: in steady state
 // almost no column holds a survivor and the whole column costs 20 VALU instructions and one
-// wave-uniform branch; a column that does is searched accumulator by accumulator.
+// wave-uniform branch; in a column that does, the lanes that hold one walk their accumulators.
 // FULL = false adds the row-range test for the last, partial row tile of a slice (its padding
 // rows repeat the last valid row).
 template <int MT, int NT, bool FULL>
@@ -173,34 +175,25 @@ __device__ __forceinline__ void filter_tile(const f32x4_t (&acc)[MT][NT], int ro
         for (int m = 1; m + 1 < MT; m += 2) mx = vmax3(mx, mm[m], mm[m + 1]);
         if ((MT & 1) == 0) mx = vmax2(mx, mm[MT - 1]);
         if (__builtin_amdgcn_ballot_w64(mx >= thr) == 0) continue;
-        // survivors in this column: count them per lane, reserve their slots with ONE LDS atomic per
-        // lane, then store them (accumulators without a survivor in any lane are skipped wave-wide)
-        unsigned long long hot[MT];
-        unsigned c = 0;
+        // Survivors in this column: typically one to three values in one or two lanes.  Only those lanes go on
+        // (the others are masked off and the compiler skips empty blocks with execz branches): accumulator by
+        // accumulator, a slot from the query's LDS counter per survivor, one store.  The order of a buffer's
+        // candidates is immaterial (the fold sorts them).
+        if (mx >= thr) {
+            skey_t* cq = cand + (size_t)ql * CAND_CAP;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            hot[m] = __builtin_amdgcn_ballot_w64(mm[m] >= thr);
-            if (hot[m] == 0) continue;
+            for (int m = 0; m < MT; ++m) {
+                if (mm[m] >= thr) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                c += (acc[m][n][i] >= thr && (FULL || row_base + m * 16 + fq * 4 + i < rows_valid)) ? 1u : 0u;
-        }
-        unsigned pos = 0;
-        if (c) {
-            pos = lds_add_rtn(&cnt_l[ql], c);
-            if (pos + c >= (unsigned)CAND_TRIG) lds_store(flag_l, 1u);
-        }
-        skey_t* cq = cand + (size_t)ql * CAND_CAP;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            if (hot[m] == 0) continue;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float s = acc[m][n][i];
-                const int rr = row_base + m * 16 + fq * 4 + i;
-                if (s >= thr && (FULL || rr < rows_valid)) {
-                    if (pos < (unsigned)CAND_CAP) cq[pos] = make_key(s, ids ? ids[rr - row_base] : (uint32_t)(row0 + rr));
-                    ++pos;
+                    for (int i = 0; i < 4; ++i) {
+                        const float s = acc[m][n][i];
+                        const int rr = row_base + m * 16 + fq * 4 + i;
+                        if (s >= thr && (FULL || rr < rows_valid)) {
+                            const unsigned pos = lds_add_rtn(&cnt_l[ql], 1u);
+                            if (pos + 1 >= (unsigned)CAND_TRIG) lds_store(flag_l, 1u);
+                            if (pos < (unsigned)CAND_CAP) cq[pos] = make_key(s, ids ? ids[rr - row_base] : (uint32_t)(row0 + rr));
+                        }
+                    }
                 }
             }
         }

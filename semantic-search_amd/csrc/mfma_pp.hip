@@ -59,7 +59,11 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
     skey_t* cand = P.cand + (size_t)blockIdx.x * TN * CAND_CAP;
 
     if (tid < 256) {
+#ifdef SSMI_STAMP_NOPASS
+        thr_l[tid] = __builtin_inff();
+#else
         thr_l[tid] = (q0 + tid < P.nq) ? SSMI_NEG_MAX : __builtin_inff();
+#endif
         cnt_l[tid] = 0;
         kept_l[tid] = 0;
     }
@@ -128,7 +132,15 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
 #define STAMP(i)
 #endif
     unsigned tiles_done = 0;
+    const size_t tile_stride = (size_t)TM * (size_t)ld * 2;
     for (long long row0 = r_begin; row0 < r_end; row0 += TM) {
+        // The ring runs on ACROSS row tiles when the next tile is whole and lies in the same storage segment
+        // (its rows are then tile_stride bytes further on, no segment lookup) and the tile's phases fill whole
+        // turns of the ring: the last three phases fetch the next tile's slabs 0..2 instead of nothing, so the
+        // fill's HBM round trip hides behind MFMAs and the epilogue instead of following it.
+        const long long next0 = row0 + TM;
+        const bool cont = (np & (RING - 1)) == 0 && np >= RING && next0 + TM <= r_end &&
+                          (row0 >> P.X.seg_shift) == ((next0 + TM - 1) >> P.X.seg_shift);
         f32x4_t acc[8][4];
 #pragma unroll
         for (int m = 0; m < 8; ++m)
@@ -148,13 +160,15 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
             // ---- LOAD segment (the partner group owns the matrix pipe meanwhile) ----
             // DMA of slab p+3 into the ring slot of slab p-1: every ds_read of slab p-1 was retired by
             // an lgkmcnt(0) that its wave executed BEFORE a barrier event this wave has already passed.
-            if (p + 3 < np) {
+            if (p + 3 < np || cont) {
                 unsigned char* dst = smem + ((p + 3) & (RING - 1)) * PHASE_LDS + (wave * 2) * 1024;
-                const size_t koff = (size_t)(p + 3) * 64;
+                const bool here = p + 3 < np;
+                const size_t qoff = (size_t)(here ? p + 3 : p + 3 - np) * 64;
+                const size_t koff = here ? qoff : tile_stride + qoff;
                 GLDS16(asrc[0] + koff, dst);
                 GLDS16(asrc[1] + koff, dst + 1024);
-                GLDS16(qsrc[0] + koff, dst + SLAB);
-                GLDS16(qsrc[1] + koff, dst + SLAB + 1024);
+                GLDS16(qsrc[0] + qoff, dst + SLAB);
+                GLDS16(qsrc[1] + qoff, dst + SLAB + 1024);
             }
             half8_t a[8], b[4];
 #pragma unroll
@@ -163,7 +177,7 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
             for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const half8_t*>(slab + b_off + n * 16 * 64);
             // own DMA of slab p+1 must have landed before this phase's first barrier; the four
             // instructions just issued (slab p+3) and the four of slab p+2 may stay in flight
-            if (p + 3 < np) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (p + 3 < np || cont) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if (p + 2 < np) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers: slab p may be recycled
@@ -184,8 +198,10 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
         STAMP(1)
 
         // start the next row tile's pipeline before the epilogue: every ring slot is free now
-        const long long next0 = row0 + TM;
-        if (next0 < r_end) {
+        if (cont) {
+            asrc[0] += tile_stride;
+            asrc[1] += tile_stride;
+        } else if (next0 < r_end) {
             set_rows(next0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ISSUE_FILL(0)
@@ -203,9 +219,26 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
         STAMP(4)
         // fold the buffers after row tiles 1, 4, 16, 64, ... of the slice and whenever one is half full
         ++tiles_done;
+#ifdef SSMI_STAMP_NOPASS
+        if (false) {
+#else
         if (((tiles_done & (tiles_done - 1)) == 0 && (tiles_done & 0x55555555u)) || *flag_l) {
+#endif
             for (int ql = wave; ql < 256; ql += 8)
                 if (q0 + ql < P.nq) compact_query<R>(ql, q0 + ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
+            // Share the thresholds between the slices of this query tile: the k-th score of ANY slice is a lower
+            // bound of the final k-th score, so every slice may filter with the highest one reached so far (its
+            // own list then holds fewer than k keys; the merge takes that).  One atomic max per query and fold,
+            // the wave's 32 queries in one round trip.
+            if (P.gthr && lane < 32) {
+                const int ql = wave + 8 * lane;
+                if (q0 + ql < P.nq) {
+                    const float t = thr_l[ql];
+                    const unsigned mine = (t > SSMI_NEG_MAX) ? f32_to_ord(t) : 0u;
+                    const unsigned seen = atomicMax(&P.gthr[q0 + ql], mine);
+                    if (seen > mine) thr_l[ql] = ord_to_f32(seen);
+                }
+            }
             __syncthreads();
             if (tid == 0) *flag_l = 0;
         }
