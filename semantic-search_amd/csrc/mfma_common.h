@@ -135,6 +135,80 @@ __device__ __forceinline__ void lds_store(unsigned* p, unsigned v) {
     asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(addr), "v"(v) : "memory");
 }
 
+// The fold of a whole 256-query tile, eight waves striding over the queries.  One fold is a chain of memory
+// round trips (candidate keys and kept list in, sorted list out) around a short sort, so each wave loads the
+// NEXT query's candidates and list before it sorts the current one, and writes its LDS words through the
+// opaque store above (no compiler-added wait for the list store in front of them).
+template <int R>
+struct FoldOperands {
+    int n;            // candidates in the buffer (clamped to its capacity)
+    unsigned has;     // the query already owns a k-list
+    skey_t c;         // candidate `lane` (the first 64)
+    skey_t kept[R];   // list element r*64 + lane, best first
+};
+template <int R>
+__device__ __forceinline__ FoldOperands<R> fold_load(int ql, const skey_t* kept, int k, const skey_t* cand_q,
+                                                     const unsigned* cnt_l, const unsigned* kept_l) {
+    const int lane = lane_id();
+    FoldOperands<R> o;
+    o.n = (int)min(cnt_l[ql], (unsigned)CAND_CAP);
+    o.has = kept_l[ql];
+    o.c = (lane < o.n) ? cand_q[lane] : 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) o.kept[r] = (o.has && r * 64 + lane < k) ? kept[r * 64 + lane] : 0;
+    return o;
+}
+template <int R>
+__device__ __forceinline__ void fold_one(int ql, const FoldOperands<R>& o, skey_t* kept, int k, const skey_t* cand_q,
+                                         float* thr_l, unsigned* cnt_l, unsigned* kept_l) {
+    const int lane = lane_id();
+    if (o.n == 0 && o.has) return;  // nothing new: list and threshold stand
+    WaveTopK<R> t;
+#pragma unroll
+    for (int r = 0; r < R; ++r) t.v[r] = o.kept[r];  // sorted best first, zero padded
+    if (o.n <= 64) {
+        WaveTopK<1> c;
+        c.v[0] = o.c;
+        c.sort_desc();
+        t.merge_regs(c);
+    } else {
+        for (int base = 0; base < o.n; base += 256) {
+            WaveTopK<4> c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = base + r * 64 + lane;
+                c.v[r] = (e < o.n) ? cand_q[e] : 0;
+            }
+            c.sort_desc();
+            t.merge_regs(c);
+        }
+    }
+    const skey_t thrk = t.kth(k);
+    t.store(kept, k);
+    if (lane == 0) {
+        lds_store(&kept_l[ql], 1u);
+        lds_store(&cnt_l[ql], 0u);
+        lds_store(reinterpret_cast<unsigned*>(&thr_l[ql]), __float_as_uint((thrk == 0) ? SSMI_NEG_MAX : key_score(thrk)));
+    }
+}
+template <int R>
+__device__ __forceinline__ void fold_queries(int wave, int q0, const MfmaParams& P, int slice, skey_t* cand,
+                                             float* thr_l, unsigned* cnt_l, unsigned* kept_l) {
+    int nql = P.nq - q0;
+    if (nql > 256) nql = 256;
+    auto list_of = [&](int ql) { return P.partial + ((size_t)(q0 + ql) * P.nslices + slice) * P.k; };
+    int ql = wave;
+    if (ql >= nql) return;
+    FoldOperands<R> cur = fold_load<R>(ql, list_of(ql), P.k, cand + (size_t)ql * CAND_CAP, cnt_l, kept_l);
+    for (; ql < nql; ql += 8) {
+        const int qn = ql + 8;
+        FoldOperands<R> nxt = cur;
+        if (qn < nql) nxt = fold_load<R>(qn, list_of(qn), P.k, cand + (size_t)qn * CAND_CAP, cnt_l, kept_l);
+        fold_one<R>(ql, cur, list_of(ql), P.k, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
+        cur = nxt;
+    }
+}
+
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
     float d;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
@@ -183,7 +257,9 @@ __device__ __forceinline__ void filter_tile(const f32x4_t (&acc)[MT][NT], int ro
             skey_t* cq = cand + (size_t)ql * CAND_CAP;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                if (mm[m] >= thr) {
+                // wave-uniform and marked unlikely: the accumulator's code is laid out of line, so the usual
+                // accumulator without a survivor costs a compare and a branch that is not taken
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(mm[m] >= thr) != 0, 0)) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float s = acc[m][n][i];

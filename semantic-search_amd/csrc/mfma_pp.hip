@@ -224,8 +224,7 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
 #else
         if (((tiles_done & (tiles_done - 1)) == 0 && (tiles_done & 0x55555555u)) || *flag_l) {
 #endif
-            for (int ql = wave; ql < 256; ql += 8)
-                if (q0 + ql < P.nq) compact_query<R>(ql, q0 + ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
+            fold_queries<R>(wave, q0, P, slice, cand, thr_l, cnt_l, kept_l);
             // Share the thresholds between the slices of this query tile: the k-th score of ANY slice is a lower
             // bound of the final k-th score, so every slice may filter with the highest one reached so far (its
             // own list then holds fewer than k keys; the merge takes that).  One atomic max per query and fold,
@@ -251,8 +250,7 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
 
     // ---- end of slice: fold what is left; the k-list is the partial result ----
     __syncthreads();
-    for (int ql = wave; ql < 256; ql += 8)
-        if (q0 + ql < P.nq) compact_query<R>(ql, q0 + ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
+    fold_queries<R>(wave, q0, P, slice, cand, thr_l, cnt_l, kept_l);
 }
 
 hipError_t launch_flat_mfma_pp(const MfmaParams& P_in, int r, int grid, size_t lds, hipStream_t s) {
