@@ -23,6 +23,10 @@
 // than a factor four in rows seen and a period adds about 3k candidates per
 // query) and whenever a buffer is half full.  At the end of the slice the k-list
 // IS the per-slice partial result that K3 (merge.hip) merges across slices.
+// After every fold the slices of a query tile exchange thresholds through `gthr`
+// (one atomic max per query): the k-th score of any slice bounds the final k-th
+// score from below, so a slice may filter with the highest one reached anywhere;
+// its own list then holds fewer than k keys, which K3 takes (key 0 = empty).
 #include "mfma_common.h"
 #include <cstdlib>
 

@@ -20,6 +20,11 @@
 //   RAW  slab p+1 is read one phase after every wave's vmcnt wait + a barrier
 //   WAR  slab p+3 overwrites slab p-1, whose last ds_reads were retired by an
 //        lgkmcnt(0) at least one barrier event earlier
+// The ring runs on across row tiles: when the next row tile is whole and lies in the
+// same storage segment, the last three phases of a tile fetch slabs 0..2 of the next
+// one (its rows are one tile stride further on), so the epilogue is not followed by a
+// pipeline fill.  Otherwise (segment boundary, last tile, phases not a multiple of the
+// ring) the fill is issued after the K loop, before the epilogue.
 // Slab image: 64-byte rows, 16-byte chunk c of row r stored at chunk
 // c ^ ((-(r >> 2)) & 3) (applied to the DMA SOURCE address and to the reads),
 // which makes every ds_read_b128 fragment read bank-conflict free.
