@@ -67,7 +67,8 @@ bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_c
 hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, const MfmaPlan& p, void* qh, void* cand,
                             skey_t* partial, hipStream_t s) {
     unsigned* gthr = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(qh) + (size_t)p.nqt * TN * X.ld * 2);
-    static const bool share_thr = !(getenv("SSMI_MFMA_SHARE_THR") && getenv("SSMI_MFMA_SHARE_THR")[0] == '0');
+    const char* env_t = getenv("SSMI_MFMA_SHARE_THR");
+    const bool share_thr = !(env_t && env_t[0] == '0');
     hipLaunchKernelGGL(cvt_queries_f16_kernel, dim3(p.nqt * TN), dim3(256), 0, s, Q, nq, X.ld, (_Float16*)qh, gthr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -72,3 +72,59 @@ def test_mfma_duplicate_rows_tie_order(ssa):
     D, I = index.search(Q, 4)
     assert index.last_timing()["last_path"] == 1
     assert (I[:, :3] == np.array([3, 500, 900])).all()
+
+
+# ---- the 256-query kernel (nq > 128) with many row tiles per slice: LDS ring running on across row tiles,
+# ---- thresholds shared between the slices of a query tile, folds and the survivor path of the filter
+@pytest.mark.parametrize("n,d,nq,k,seg_shift", [
+    (140000, 256, 300, 10, None),   # 5 row tiles per slice, 8 phases per tile: ring runs on across tiles
+    (140000, 256, 300, 100, None),  # same with two-register lists
+    (50000, 192, 300, 10, None),    # 6 phases per tile: not whole turns of the ring, fill after the K loop
+    (140003, 256, 600, 10, 10),     # 1024-row segments: every fourth tile boundary is a segment boundary; ragged tail
+    (70000, 1024, 1100, 10, None),  # five query tiles
+])
+def test_wide_kernel_many_row_tiles(ssa, monkeypatch, n, d, nq, k, seg_shift):
+    if seg_shift is not None:
+        monkeypatch.setenv("SSMI_SEG_SHIFT", str(seg_shift))
+    X, Q = unit_rows(n, d, 77), unit_rows(nq, d, 78)
+    index = ssa.IndexFlatIP(d, storage="f16")
+    index.add(X)
+    D, I = index.search(Q, k)
+    assert index.last_timing()["last_path"] == 1
+    Xh, Qh = r16(X), r16(Q)
+    Dr, Ir = flat_ip.search(Xh, Qh, k)
+    ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xh, Qh, rtol=1e-5, tie_rtol=1e-5)
+    assert ok, msg
+    # the same search with every slice keeping its thresholds to itself
+    monkeypatch.setenv("SSMI_MFMA_SHARE_THR", "0")
+    index2 = ssa.IndexFlatIP(d, storage="f16")
+    index2.add(X)
+    D2, I2 = index2.search(Q, k)
+    ok, msg, _ = flat_ip.check_against(D2, I2, Dr, Ir, Xh, Qh, rtol=1e-5, tie_rtol=1e-5)
+    assert ok, msg
+    index.close(); index2.close()
+
+
+@pytest.mark.parametrize("k", [10, 100])
+def test_wide_kernel_best_rows_in_one_slice(ssa, k):
+    """All good rows sit in the first slice: the other slices inherit a threshold above every score they
+    hold and hand empty or short lists to the merge."""
+    n, d, nq = 140000, 256, 300
+    rng = np.random.default_rng(5)
+    u = unit_rows(1, d, 9)[0]
+    X = unit_rows(n, d, 10)
+    good = u[None, :] + 0.15 * rng.standard_normal((600, d)).astype(np.float32)
+    X[:600] = good / np.linalg.norm(good, axis=1, keepdims=True)
+    Q = u[None, :] + 0.05 * rng.standard_normal((nq, d)).astype(np.float32)
+    Q = (Q / np.linalg.norm(Q, axis=1, keepdims=True)).astype(np.float32)
+    index = ssa.IndexFlatIP(d, storage="f16")
+    index.add(X)
+    for _ in range(2):  # thresholds travel between workgroups: the result must not depend on their timing
+        D, I = index.search(Q, k)
+        assert index.last_timing()["last_path"] == 1
+        Xh, Qh = r16(X), r16(Q)
+        Dr, Ir = flat_ip.search(Xh, Qh, k)
+        ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xh, Qh, rtol=1e-5, tie_rtol=1e-5)
+        assert ok, msg
+        assert (I[:, :min(k, 100)] < 600).all()
+    index.close()
