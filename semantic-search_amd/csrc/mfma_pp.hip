@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
     }
 
 #ifdef SSMI_STAMP
-    unsigned long long stv[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long stv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stv[i] += now_ - stl_; stl_ = now_; }
     unsigned long long stl_ = __builtin_amdgcn_s_memtime();
 #else
@@ -230,6 +230,7 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
         if (((tiles_done & (tiles_done - 1)) == 0 && (tiles_done & 0x55555555u)) || *flag_l) {
 #endif
             fold_queries<R>(wave, q0, P, slice, cand, thr_l, cnt_l, kept_l);
+            STAMP(5)
             // Share the thresholds between the slices of this query tile: the k-th score of ANY slice is a lower
             // bound of the final k-th score, so every slice may filter with the highest one reached so far (its
             // own list then holds fewer than k keys; the merge takes that).  One atomic max per query and fold,
@@ -243,14 +244,15 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
                     if (seen > mine) thr_l[ql] = ord_to_f32(seen);
                 }
             }
+            STAMP(6)
             __syncthreads();
             if (tid == 0) *flag_l = 0;
         }
-        STAMP(5)
+        STAMP(7)
     }
 #ifdef SSMI_STAMP
     if (lane == 0 && P.dbg)
-        for (int i = 0; i < 6; ++i) P.dbg[((size_t)blockIdx.x * 8 + wave) * 6 + i] = stv[i];
+        for (int i = 0; i < 8; ++i) P.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = stv[i];
 #endif
 
     // ---- end of slice: fold what is left; the k-list is the partial result ----
@@ -263,7 +265,7 @@ hipError_t launch_flat_mfma_pp(const MfmaParams& P_in, int r, int grid, size_t l
     MfmaParams P = P_in;
 #ifdef SSMI_STAMP
     static unsigned long long* dbg = nullptr;
-    if (!dbg) (void)hipMalloc((void**)&dbg, 4096 * 8 * 6 * 8);
+    if (!dbg) (void)hipMalloc((void**)&dbg, 4096 * 8 * 8 * 8);
     P.dbg = dbg;
 #endif
 #define LAUNCH_R(RR)                                                                                    \
@@ -282,23 +284,23 @@ hipError_t launch_flat_mfma_pp(const MfmaParams& P_in, int r, int grid, size_t l
 #ifdef SSMI_STAMP
     {
         (void)hipStreamSynchronize(s);
-        std::vector<unsigned long long> h((size_t)grid * 48);
+        std::vector<unsigned long long> h((size_t)grid * 64);
         (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
-        const char* names[6] = {"wait", "loop", "prefetch", "filter", "sync", "compact"};
+        const char* names[8] = {"wait", "loop", "prefetch", "filter", "sync", "fold", "exchange", "fold_sync"};
         {   // how evenly do the workgroups finish?  (sum of all stamped segments of wave 0 per workgroup)
             double mn = 1e30, mx = 0, sum = 0;
             for (int b = 0; b < grid; ++b) {
                 double t = 0;
-                for (int i = 0; i < 6; ++i) t += (double)h[((size_t)b * 8) * 6 + i];
+                for (int i = 0; i < 8; ++i) t += (double)h[((size_t)b * 8) * 8 + i];
                 mn = std::min(mn, t); mx = std::max(mx, t); sum += t;
             }
             fprintf(stderr, "[stamp] workgroup totals (cycles): min %.0f mean %.0f max %.0f\n", mn, sum / grid, mx);
         }
         for (int w : {0, 4}) {
             fprintf(stderr, "[stamp] wave %d:", w);
-            for (int i = 0; i < 6; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 double sum = 0;
-                for (int b = 0; b < grid; ++b) sum += (double)h[((size_t)b * 8 + w) * 6 + i];
+                for (int b = 0; b < grid; ++b) sum += (double)h[((size_t)b * 8 + w) * 8 + i];
                 fprintf(stderr, " %s %.0f", names[i], sum / grid);
             }
             fprintf(stderr, "\n");
