@@ -138,16 +138,20 @@ static int create_common(int d, int storage_dtype, int device, int kind, ssmi_in
     if (device < 0 || device >= ndev) return fail("device %d not available (%d visible)", device, ndev);
     DeviceGuard g(device);
     if (!g.ok) return fail("hipSetDevice(%d) failed", device);
-    ssmi_index* h = new ssmi_index();
+    // everything below may fail half-way: the guard hands a partly built handle to ssmi_index_free (which
+    // takes zeroed members) unless the construction completes
+    struct Guard {
+        ssmi_index* h;
+        ~Guard() { if (h) ssmi_index_free(h); }
+    } guard{new ssmi_index()};
+    ssmi_index* h = guard.h;
     h->kind = kind;
     h->device = device;
     hipDeviceProp_t prop;
     HIPCHECK(hipGetDeviceProperties(&prop, device));
     h->num_cu = prop.multiProcessorCount;
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        delete h;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail("libssmi is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
-    }
     HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (int i = 0; i < ssmi_index::kEvRing; ++i)
         for (int j = 0; j < 3; ++j) HIPCHECK(hipEventCreate(&h->ev[i][j]));
@@ -156,7 +160,8 @@ static int create_common(int d, int storage_dtype, int device, int kind, ssmi_in
         HIPCHECK(hipMemset(h->tail_counters, 0, ssmi_index::kTailCounters * sizeof(unsigned)));
     }
     if (const char* e = getenv("SSMI_TIMING")) h->timing_on = e[0] != '0';
-    if (h->rows.init(d, storage_dtype)) { delete h; return 1; }
+    CHECK(h->rows.init(d, storage_dtype));
+    guard.h = nullptr;
     *out = h;
     return 0;
 }
