@@ -112,6 +112,20 @@ int ssmi_index_search(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind,
                       int k, float* D, int64_t* I, int out_mem_kind,
                       int64_t id_offset, void* stream);
 
+/* Allocation-free variant of ssmi_index_search.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
+ * cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  Flat indexes whose dimension is a multiple of 8; q, D, I are DEVICE buffers; work is enqueued on
+ * `stream` (NULL = the HIP null stream) and the call returns after enqueueing.  Always the exact streaming scan
+ * (K1 + merge tail) whatever the batch size.  The kernels' scratch (per-block partial k-lists, ticket counters)
+ * lives in one file-scope device array of SSMI_STATIC_SCRATCH_BYTES per GPU, held until the process ends; the
+ * call fails with a clear message when nq * row_slices * k * 8 bytes exceed it (row_slices <= 2 * CUs; k=10 on
+ * 256 slices: ~400 queries, k=1024: 3) and never calls hipMalloc/hipFree.  All calls on one GPU share that
+ * array: calls that overlap on one GPU (two streams, two handles, two threads) race; serialise them. */
+#define SSMI_STATIC_SCRATCH_BYTES (8u << 20)
+int ssmi_index_search_static(ssmi_index* h, int64_t nq, const float* q_dev, int k, float* D_dev, int64_t* I_dev,
+                             int64_t id_offset, void* stream);
+int ssmi_static_scratch_bytes(size_t* out);
+
 /* merge step of a sharded search (the RCCL all-gather's consumer; no reference
  * counterpart - the reference is single-index).  Inputs are `nlists` result
  * sets on the device, each (nq,k) row-major; set l starts at D_lists +

@@ -62,6 +62,9 @@ _SIGNATURES = {
     "ssmi_index_add_random_unit": [_c_index_p, ctypes.c_int64, ctypes.c_uint64],
     "ssmi_index_search": [_c_index_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                           ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p],
+    "ssmi_index_search_static": [_c_index_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                 ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p],
+    "ssmi_static_scratch_bytes": [ctypes.POINTER(ctypes.c_size_t)],
     "ssmi_topk_merge": [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
                         ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
     "ssmi_index_reconstruct_n": [_c_index_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p],

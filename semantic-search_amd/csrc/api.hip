@@ -152,6 +152,7 @@ static int create_common(int d, int storage_dtype, int device, int kind, ssmi_in
     h->num_cu = prop.multiProcessorCount;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail("libssmi is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+    CHECK(static_scratch_setup(device));  // ssmi_index_search_static's per-device scratch address
     HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (int i = 0; i < ssmi_index::kEvRing; ++i)
         for (int j = 0; j < 3; ++j) HIPCHECK(hipEventCreate(&h->ev[i][j]));

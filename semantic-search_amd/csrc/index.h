@@ -109,6 +109,9 @@ struct ProbePlanRequest {
 int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev, int k, float* Ddev, int64_t* Idev,
                  int64_t id_offset, hipStream_t s, bool record, ProbePlanRequest* plan = nullptr);
 
+// static_search.hip: resolves this device's copy of the static scratch array (once per device, device current)
+int static_scratch_setup(int device);
+
 // IVF entry points (ivf.hip)
 int ivf_create(ssmi_index* h, int nlist);
 void ivf_destroy(ssmi_index* h);

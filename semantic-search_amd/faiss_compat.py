@@ -193,6 +193,23 @@ class _IndexBase:
                                                I.ctypes.data, _lib.HOST, int(id_offset), None))
         return D, I
 
+    def search_static(self, x: torch.Tensor, k: int, out, id_offset: int = 0) -> None:
+        """Allocation-free search (ssmi_index_search_static; no counterpart in the reference): x (nq,d) float32 and
+        out=(D,I) are contiguous tensors on the index's device; enqueued on the current torch stream.  Nothing is
+        allocated, on the device or by torch: the kernels' scratch is a fixed per-GPU array inside libssmi, shared
+        by every call on that GPU (overlapping calls race)."""
+        D, I = out
+        nq = x.shape[0]
+        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2):
+            raise ValueError("search_static: x must be a contiguous 2-D float32 tensor on the index's device")
+        if (tuple(D.shape) != (nq, k) or tuple(I.shape) != (nq, k) or D.dtype != torch.float32 or I.dtype != torch.int64
+                or not D.is_contiguous() or not I.is_contiguous() or D.device != x.device or I.device != x.device):
+            raise ValueError("search_static: out must be contiguous (nq,k) float32 / int64 tensors on the index's device")
+        self._check_tensor(x, "search_static")
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(self._lib.ssmi_index_search_static(self._handle(), nq, x.data_ptr(), int(k), D.data_ptr(),
+                                                      I.data_ptr(), int(id_offset), stream))
+
     # -- read back --------------------------------------------------------
     def reconstruct_batch(self, ids) -> np.ndarray:
         ids = np.ascontiguousarray(np.asarray(ids, dtype=np.int64).reshape(-1))
