@@ -94,6 +94,14 @@ int ssmi_index_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int m
  * list l has l % nshards == shard, stored under the global ids id0 + i. */
 int ssmi_index_add_ivf_shard(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind,
                              int64_t id0, int shard, int nshards);
+/* The same sharding without redundant work (no reference counterpart; multi-GPU add of sharded.py): a rank
+ * assigns only ITS slice of the incoming vectors (ssmi_index_assign: list of the max-inner-product centroid per
+ * vector, what IndexIVFFlat.add computes internally), the ranks exchange (vector, list, global id) triples so
+ * that each list's members reach the rank that owns the list, and the owner appends what it received with
+ * ssmi_index_add_preassigned.  labels/ids are host arrays; x is (n,d) of src_dtype, host or device. */
+int ssmi_index_assign(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind, int32_t* labels_out_host);
+int ssmi_index_add_preassigned(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind,
+                               const int32_t* labels_host, const int64_t* ids_host);
 /* bench/test helper (no reference counterpart): append n rows of i.i.d.
  * N(0,1) components, L2-normalised per row, generated on the device. */
 int ssmi_index_add_random_unit(ssmi_index* h, int64_t n, uint64_t seed);

@@ -59,6 +59,9 @@ _SIGNATURES = {
     "ssmi_index_add": [_c_index_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int],
     "ssmi_index_add_ivf_shard": [_c_index_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                  ctypes.c_int, ctypes.c_int],
+    "ssmi_index_assign": [_c_index_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
+    "ssmi_index_add_preassigned": [_c_index_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                   ctypes.c_void_p],
     "ssmi_index_add_random_unit": [_c_index_p, ctypes.c_int64, ctypes.c_uint64],
     "ssmi_index_search": [_c_index_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                           ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p],

@@ -682,53 +682,69 @@ static int ensure_slots(ssmi_index* h, long long npages) {
     return 0;
 }
 
-// append vectors (on the device as (n, ld) fp32) to given lists; ids == nullptr: sequential ids from ntotal
+// append vectors (on the device as (n, ld) fp32) to given lists; ids == nullptr: sequential ids from ntotal.
+// The host-side list state (sizes, page tables, direct map) is committed only when every step that can fail
+// (slot store growth, workspace, launches) has succeeded; a failed add leaves the index as it was.
 int ivf_append_preassigned(ssmi_index* h, int64_t n, const float* xdev, const int* labels, const uint32_t* ids_host,
                            const int* src_idx_host) {
     if (n == 0) return 0;
     IvfState* S = st(h);
     std::vector<int> dst((size_t)n);
+    std::vector<unsigned char> pushed((size_t)n, 0);
+    const size_t dm_size0 = S->direct_map.size();
     for (int64_t i = 0; i < n; ++i) {
         const int l = labels[i];
         const long long pos = S->size[l];
-        if ((pos & (kPageRows - 1)) == 0) S->pages[l].push_back((int)S->npages++);
+        if ((pos & (kPageRows - 1)) == 0) { S->pages[l].push_back((int)S->npages++); pushed[i] = 1; }
         const long long slot = (long long)S->pages[l][pos >> kPageShift] * kPageRows + (pos & (kPageRows - 1));
         dst[i] = (int)slot;
         S->size[l] = pos + 1;
         if (S->has_direct_map && !ids_host) S->direct_map.push_back(slot);
     }
-    if (S->npages * kPageRows >= (1ll << 31)) return fail("IVF slot store would exceed 2^31 slots");
-    CHECK(ensure_slots(h, S->npages));
-    CHECK(ensure_ws(h, 9, (size_t)n * 12));
-    HIPCHECK(hipMemcpyAsync(h->ws[9], dst.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-    const uint32_t* ids_dev = nullptr;
-    const int* src_idx_dev = nullptr;
-    if (ids_host) {
-        ids_dev = (const uint32_t*)((char*)h->ws[9] + (size_t)n * 4);
-        HIPCHECK(hipMemcpyAsync((void*)ids_dev, ids_host, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-    }
-    if (src_idx_host) {
-        src_idx_dev = (const int*)((char*)h->ws[9] + (size_t)n * 8);
-        HIPCHECK(hipMemcpyAsync((void*)src_idx_dev, src_idx_host, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-    }
-    const RowStore& R = h->rows;
-    if (R.dtype == SSMI_F32)
-        hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)h->ws[9],
-                           (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, (uint32_t)h->ivf_ntotal, ids_dev, src_idx_dev);
-    else
-        hipLaunchKernelGGL((scatter_rows_kernel<__half>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)h->ws[9],
-                           (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, (uint32_t)h->ivf_ntotal, ids_dev, src_idx_dev);
-    HIPCHECK(hipGetLastError());
-    if (h->has_shadow && R.dtype == SSMI_F32) {
-        // the fp16 shadow of the slot store (built by the first batched search, see ivf_search) follows every add
-        RowStore& H = h->shadow16;
-        CHECK(H.reserve(R.nrows, h->stream));
-        hipLaunchKernelGGL((scatter_rows_kernel<__half>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)h->ws[9],
-                           (void* const*)H.d_segs, H.seg_shift, S->d_slot_ids, (uint32_t)h->ivf_ntotal, ids_dev, src_idx_dev);
+    auto rollback = [&]() {
+        for (int64_t i = n - 1; i >= 0; --i) {
+            const int l = labels[i];
+            S->size[l] -= 1;
+            if (pushed[i]) { S->pages[l].pop_back(); S->npages--; }
+        }
+        S->direct_map.resize(dm_size0);
+    };
+    auto body = [&]() -> int {
+        if (S->npages * kPageRows >= (1ll << 31)) return fail("IVF slot store would exceed 2^31 slots");
+        CHECK(ensure_slots(h, S->npages));
+        CHECK(ensure_ws(h, 9, (size_t)n * 12));
+        HIPCHECK(hipMemcpyAsync(h->ws[9], dst.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+        const uint32_t* ids_dev = nullptr;
+        const int* src_idx_dev = nullptr;
+        if (ids_host) {
+            ids_dev = (const uint32_t*)((char*)h->ws[9] + (size_t)n * 4);
+            HIPCHECK(hipMemcpyAsync((void*)ids_dev, ids_host, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+        }
+        if (src_idx_host) {
+            src_idx_dev = (const int*)((char*)h->ws[9] + (size_t)n * 8);
+            HIPCHECK(hipMemcpyAsync((void*)src_idx_dev, src_idx_host, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+        }
+        const RowStore& R = h->rows;
+        if (R.dtype == SSMI_F32)
+            hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)h->ws[9],
+                               (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, (uint32_t)h->ivf_ntotal, ids_dev, src_idx_dev);
+        else
+            hipLaunchKernelGGL((scatter_rows_kernel<__half>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)h->ws[9],
+                               (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, (uint32_t)h->ivf_ntotal, ids_dev, src_idx_dev);
         HIPCHECK(hipGetLastError());
-        H.nrows = R.nrows;
-    }
-    HIPCHECK(hipStreamSynchronize(h->stream));
+        if (h->has_shadow && R.dtype == SSMI_F32) {
+            // the fp16 shadow of the slot store (built by the first batched search, see ivf_search) follows every add
+            RowStore& H = h->shadow16;
+            CHECK(H.reserve(R.nrows, h->stream));
+            hipLaunchKernelGGL((scatter_rows_kernel<__half>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)h->ws[9],
+                               (void* const*)H.d_segs, H.seg_shift, S->d_slot_ids, (uint32_t)h->ivf_ntotal, ids_dev, src_idx_dev);
+            HIPCHECK(hipGetLastError());
+            H.nrows = R.nrows;
+        }
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        return 0;
+    };
+    if (body()) { rollback(); return 1; }
     h->ivf_ntotal += n;
     S->csr_dirty = true;
     return 0;
@@ -1118,6 +1134,62 @@ int ssmi_index_add_ivf_shard(ssmi_index* h, int64_t n, const void* x, int src_dt
     if (mem_kind != SSMI_HOST && mem_kind != SSMI_DEVICE) return fail("unknown mem_kind %d", mem_kind);
     DeviceGuard g(h->device);
     return ivf_add_shard(h, n, x, src_dtype, mem_kind, id0, shard, nshards);
+}
+
+int ssmi_index_assign(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind, int32_t* labels_out_host) {
+    if (!h) return fail("NULL index");
+    if (h->kind != SSMI_KIND_IVFFLAT) return fail("assign: not an IVF index");
+    if (!h->trained) return fail("assign on an untrained IVF index (call train first)");
+    if (n < 0) return fail("negative n");
+    if (n == 0) return 0;
+    if (!x || !labels_out_host) return fail("NULL buffer");
+    if (src_dtype != SSMI_F32 && src_dtype != SSMI_F16) return fail("unknown source dtype %d", src_dtype);
+    if (mem_kind != SSMI_HOST && mem_kind != SSMI_DEVICE) return fail("unknown mem_kind %d", mem_kind);
+    DeviceGuard g(h->device);
+    const RowStore& R = h->rows;
+    const size_t el = src_dtype == SSMI_F32 ? 4 : 2;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(1 << 16, ((size_t)1 << 30) / ((size_t)R.ld * 4)));
+    std::vector<int> labels;
+    for (int64_t done = 0; done < n; done += chunk) {
+        const int64_t cnt = std::min(chunk, n - done);
+        const float* xdev = nullptr;
+        CHECK(rows_to_device_f32(h, cnt, (const char*)x + (size_t)done * R.d * el, src_dtype, mem_kind, &xdev));
+        CHECK(assign_to_centroids(h, cnt, xdev, &labels));
+        std::copy(labels.begin(), labels.end(), labels_out_host + done);
+    }
+    return 0;
+}
+
+int ssmi_index_add_preassigned(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind,
+                               const int32_t* labels_host, const int64_t* ids_host) {
+    if (!h) return fail("NULL index");
+    if (h->kind != SSMI_KIND_IVFFLAT) return fail("add_preassigned: not an IVF index");
+    if (!h->trained) return fail("add on an untrained IVF index (call train first)");
+    if (n < 0) return fail("negative n");
+    if (n == 0) return 0;
+    if (!x || !labels_host || !ids_host) return fail("NULL buffer");
+    if (src_dtype != SSMI_F32 && src_dtype != SSMI_F16) return fail("unknown source dtype %d", src_dtype);
+    if (mem_kind != SSMI_HOST && mem_kind != SSMI_DEVICE) return fail("unknown mem_kind %d", mem_kind);
+    if (st(h)->has_direct_map) return fail("an index filled with explicit ids cannot maintain a direct map");
+    std::vector<uint32_t> ids32((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (labels_host[i] < 0 || labels_host[i] >= h->nlist)
+            return fail("add_preassigned: list %d of vector %lld out of range [0, %d)", labels_host[i], (long long)i, h->nlist);
+        if (ids_host[i] < 0 || (unsigned long long)ids_host[i] >= 0xFFFFFFFFull)
+            return fail("add_preassigned: id %lld out of range [0, 2^32-1)", (long long)ids_host[i]);
+        ids32[(size_t)i] = (uint32_t)ids_host[i];
+    }
+    DeviceGuard g(h->device);
+    const RowStore& R = h->rows;
+    const size_t el = src_dtype == SSMI_F32 ? 4 : 2;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(1 << 16, ((size_t)1 << 30) / ((size_t)R.ld * 4)));
+    for (int64_t done = 0; done < n; done += chunk) {
+        const int64_t cnt = std::min(chunk, n - done);
+        const float* xdev = nullptr;
+        CHECK(rows_to_device_f32(h, cnt, (const char*)x + (size_t)done * R.d * el, src_dtype, mem_kind, &xdev));
+        CHECK(ivf_append_preassigned(h, cnt, xdev, labels_host + done, ids32.data() + done, nullptr));
+    }
+    return 0;
 }
 
 int ssmi_index_get_list_sizes(const ssmi_index* h, int64_t* out_host) {

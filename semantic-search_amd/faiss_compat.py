@@ -313,6 +313,37 @@ class IndexIVFFlat(_IndexBase):
         _lib.check(self._lib.ssmi_index_add_ivf_shard(self._handle(), x.shape[0], x.ctypes.data, _lib.F32, _lib.HOST,
                                                       int(id0), int(shard), int(nshards)))
 
+    def _vectors_arg(self, x, what: str):
+        """(keepalive, pointer, n, src dtype, mem kind) of a numpy array / CPU tensor / device tensor of vectors."""
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            self._check_tensor(x, what)
+            if x.dtype not in (torch.float32, torch.float16):
+                x = x.float()
+            x = x.contiguous()
+            torch.cuda.current_stream(x.device).synchronize()  # the library works on its own stream
+            return x, x.data_ptr(), x.shape[0], (_lib.F32 if x.dtype == torch.float32 else _lib.F16), _lib.DEVICE
+        if isinstance(x, torch.Tensor):
+            x = x.numpy()
+        x = _as_f32_matrix(x, self.d, what)
+        return x, x.ctypes.data, x.shape[0], _lib.F32, _lib.HOST
+
+    def assign(self, x) -> np.ndarray:
+        """List (max-inner-product centroid) of every row of x, int32 (n,): the assignment step of add()
+        on its own, for the routed multi-GPU add (sharded.ShardedIVFFlat.add_local)."""
+        keep, ptr, n, dt, mk = self._vectors_arg(x, "assign")
+        out = np.empty((n,), dtype=np.int32)
+        _lib.check(self._lib.ssmi_index_assign(self._handle(), n, ptr, dt, mk, out.ctypes.data))
+        return out
+
+    def add_preassigned(self, x, labels, ids) -> None:
+        """Append rows of x to the given lists under the given (global) ids: the owner's half of the routed add."""
+        keep, ptr, n, dt, mk = self._vectors_arg(x, "add_preassigned")
+        labels = np.ascontiguousarray(np.asarray(labels, dtype=np.int32).reshape(-1))
+        ids = np.ascontiguousarray(np.asarray(ids, dtype=np.int64).reshape(-1))
+        if labels.shape[0] != n or ids.shape[0] != n:
+            raise ValueError("add_preassigned: labels and ids must have one entry per vector")
+        _lib.check(self._lib.ssmi_index_add_preassigned(self._handle(), n, ptr, dt, mk, labels.ctypes.data, ids.ctypes.data))
+
     def make_direct_map(self, _enable: bool = True) -> None:
         """Like faiss: without a direct map reconstruct() raises RuntimeError."""
         _lib.check(self._lib.ssmi_index_make_direct_map(self._handle()))

@@ -1,4 +1,4 @@
-"""Row-sharded Flat search across the GPUs of one node: one process per GPU.
+"""Row-sharded Flat search and list-sharded IVF search across the GPUs of one node: one process per GPU.
 
 Each rank owns one contiguous block of database rows in its own IndexFlatIP
 (global id = local row + the rank's row offset, which keeps the reference's
@@ -13,6 +13,7 @@ The reference has no distributed code; this is new.
 import os
 from typing import Callable, List, Optional, Tuple
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -131,26 +132,66 @@ class _Pipeline:
         return D, I
 
 
-class ShardedFlatIP:
+MAX_GLOBAL_IDS = 0xFFFFFFFF  # merge keys carry 32-bit ids (csrc/common.h): global ids must stay below 2^32-1
+
+
+def _comm_device(group=None):
+    """Device the collectives of this process group move tensors on (RCCL: the current GPU; gloo: CPU)."""
+    backend = dist.get_backend(group) if dist.is_initialized() else "gloo"
+    return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+
+
+class _ShardedSearch:
+    """The search half both sharded classes share: local top-k -> ONE all-gather -> merge."""
+
+    def _init_search(self, group, local, merge, real: bool) -> None:
+        self.group = group
+        self.local = local
+        self._merge = merge
+        self._real = real  # the HIP index (not a test double): queries must be device tensors on its GPU
+        self._pipe = None
+        self._force_pipeline = False  # tests: run the gather/merge path even with one rank
+        self._pipelined = os.environ.get("SSMI_SHARD_PIPELINE", "0") == "1"
+
+    def _check_query(self, q) -> None:
+        if not self._real:
+            return
+        if not (isinstance(q, torch.Tensor) and q.is_cuda and q.device.index == self.local.device):
+            raise ValueError("sharded search: q must be a torch tensor on this rank's GPU (cuda:%d): the per-rank "
+                             "results are all-gathered over RCCL from device buffers" % self.local.device)
+
+    def _search(self, q, k: int, id_offset: int):
+        if self.world == 1 and not self._force_pipeline:
+            return self.local.search(q, k, id_offset=id_offset)
+        self._check_query(q)
+        if q.is_cuda and self._pipelined:
+            if self._pipe is None:
+                self._pipe = _Pipeline(q.device)
+            return self._pipe.run(lambda qq, kk, out: self.local.search(qq, kk, id_offset=id_offset, out=out),
+                                  self._merge, q, k, self.group)
+        B = q.shape[0] if q.dim() == 2 else 1
+        buf, D, I = packed_result_buffers(B, k, q.device)
+        self.local.search(q, k, id_offset=id_offset, out=(D, I))
+        Dg, Ig = gather_packed(buf, B, k, self.group)
+        return self._merge(Dg, Ig)
+
+
+class ShardedFlatIP(_ShardedSearch):
     """Exact inner-product search over a database row-sharded across ranks."""
 
     def __init__(self, d: int, storage: str = "f32", group=None, device: Optional[int] = None,
                  _local_index=None, _merge: Optional[Callable] = None):
         self.d = d
-        self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        if _local_index is None:
+        real = _local_index is None
+        if real:
             from .faiss_compat import IndexFlatIP, topk_merge
             _local_index = IndexFlatIP(d, storage=storage, device=device)
             _merge = topk_merge
-        self.local = _local_index
-        self._merge = _merge
+        self._init_search(group, _local_index, _merge, real)
         self.row_offset = 0
         self.ntotal = 0
-        self._pipe = None
-        self._force_pipeline = False  # tests: run the gather/merge path even with one rank
-        self._pipelined = os.environ.get("SSMI_SHARD_PIPELINE", "0") == "1"
 
     def add_local(self, x) -> None:
         self.local.add(x)
@@ -164,41 +205,40 @@ class ShardedFlatIP:
             self.row_offset, self.ntotal = exchange_offsets(self.local.ntotal, self.group, device)
         else:
             self.row_offset, self.ntotal = 0, self.local.ntotal
+        if self.ntotal >= MAX_GLOBAL_IDS:
+            raise RuntimeError("sharded index holds %d rows: global ids must stay below 2^32-1" % self.ntotal)
 
     def search(self, q, k: int):
         """q: (B,d) tensor, identical on every rank.  Returns the global (D, I) on every rank."""
-        if self.world == 1 and not self._force_pipeline:
-            return self.local.search(q, k, id_offset=self.row_offset)
-        if q.is_cuda and self._pipelined:
-            if self._pipe is None:
-                self._pipe = _Pipeline(q.device)
-            return self._pipe.run(lambda qq, kk, out: self.local.search(qq, kk, id_offset=self.row_offset, out=out),
-                                  self._merge, q, k, self.group)
-        B = q.shape[0] if q.dim() == 2 else 1
-        buf, D, I = packed_result_buffers(B, k, q.device)
-        self.local.search(q, k, id_offset=self.row_offset, out=(D, I))
-        Dg, Ig = gather_packed(buf, B, k, self.group)
-        return self._merge(Dg, Ig)
+        return self._search(q, k, self.row_offset)
 
 
-class ShardedIVFFlat:
+class ShardedIVFFlat(_ShardedSearch):
     """IVF-Flat sharded BY LIST across ranks: every rank holds the same centroids, list l lives
-    wholly on rank l % world.  Every rank passes the same vectors to add() (as the reference's
-    single add stream would) and keeps its own lists' members under global ids; a search probes
-    the same nprobe lists everywhere, each rank scans the probed lists it owns (the others are
-    empty locally), and the per-rank top-k are all-gathered and merged like the Flat case."""
+    wholly on rank l % world under global ids.
+
+    add_local(x): every rank passes ITS OWN vectors (a slice of the incoming stream, or rows it generated):
+    the rank assigns only those to lists, the ranks exchange (vector, list, id) triples with one all-to-all
+    so that each list's members reach the owning rank, and the owner appends them.  Each vector is assigned
+    once, on one rank, and need not exist anywhere else.  add(x) is the reference-shaped form (one add stream,
+    core/index_manager.py:319): every rank passes the same x and takes a contiguous 1/world slice of it.
+    A search probes the same nprobe lists everywhere, each rank scans the probed lists it owns (the others
+    are empty locally), and the per-rank top-k are all-gathered and merged like the Flat case."""
 
     def __init__(self, d: int, nlist: int, storage: str = "f32", group=None, device: Optional[int] = None,
-                 rank: Optional[int] = None, world: Optional[int] = None):
-        from .faiss_compat import IndexFlatIP, IndexIVFFlat, METRIC_INNER_PRODUCT, topk_merge
-        self.d, self.nlist, self.group = d, nlist, group
+                 rank: Optional[int] = None, world: Optional[int] = None, _local_index=None,
+                 _merge: Optional[Callable] = None):
+        self.d, self.nlist = d, nlist
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.rank = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
-        self.local = IndexIVFFlat(IndexFlatIP(d, storage=storage, device=device), d, nlist, METRIC_INNER_PRODUCT,
-                                  storage=storage, device=device)
-        self._merge = topk_merge
+        real = _local_index is None
+        if real:
+            from .faiss_compat import IndexFlatIP, IndexIVFFlat, METRIC_INNER_PRODUCT, topk_merge
+            _local_index = IndexIVFFlat(IndexFlatIP(d, storage=storage, device=device), d, nlist, METRIC_INNER_PRODUCT,
+                                        storage=storage, device=device)
+            _merge = topk_merge
+        self._init_search(group, _local_index, _merge, real)
         self.ntotal = 0
-        self._pipe = None
 
     @property
     def nprobe(self) -> int:
@@ -212,12 +252,16 @@ class ShardedIVFFlat:
     def is_trained(self) -> bool:
         return self.local.is_trained
 
+    def _collective(self) -> bool:
+        # _force_pipeline: a one-rank group rehearses the collectives of the routed add as well (tests, bench)
+        return dist.is_initialized() and (self.world > 1 or self._force_pipeline)
+
     def train(self, x) -> None:
         """Rank 0 runs k-means; the centroids are broadcast so that every rank quantizes identically."""
-        if self.world == 1 or not dist.is_initialized():
+        if not self._collective():
             self.local.train(x)
             return
-        dev = torch.device("cuda", self.local.device)
+        dev = _comm_device(self.group)
         c = torch.empty((self.nlist, self.d), dtype=torch.float32, device=dev)
         if self.rank == 0:
             self.local.train(x)
@@ -227,13 +271,64 @@ class ShardedIVFFlat:
             self.local.set_centroids(c.cpu().numpy())
 
     def add(self, x) -> None:
+        """Every rank passes the same x (ids ntotal .. ntotal+n-1 in x's order)."""
         n = int(x.shape[0])
-        self.local.add_shard(x, self.ntotal, self.rank, self.world)
-        self.ntotal += n
+        if not self._collective():
+            # one process standing for one rank of a logical sharding (tests): keep the own lists' members
+            self.local.add_shard(x, self.ntotal, self.rank, self.world)
+            self.ntotal += n
+            return
+        b = shard_bounds(n, self.world)
+        self.add_local(x[b[self.rank]:b[self.rank + 1]])
+
+    def add_local(self, x) -> None:
+        """x: (n_r, d) vectors of THIS rank (numpy, CPU tensor or device tensor).  Global ids continue from
+        ntotal in rank order: rank r's vectors follow those of ranks < r."""
+        if not self._collective():
+            n = int(x.shape[0])
+            self.local.add_preassigned(x, self.local.assign(x), np.arange(self.ntotal, self.ntotal + n, dtype=np.int64))
+            self.ntotal += n
+            return
+        world, rank, group = self.world, self.rank, self.group
+        dev = _comm_device(group)
+        if not isinstance(x, torch.Tensor):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        n = int(x.shape[0])
+        labels = torch.from_numpy(self.local.assign(x).astype(np.int64)) if n else torch.zeros((0,), dtype=torch.int64)
+        # id base of this rank and the new global total
+        counts = torch.zeros((world,), dtype=torch.int64, device=dev)
+        mine = torch.tensor([n], dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(counts, mine, group=group)
+        counts = counts.cpu()
+        id0 = self.ntotal + int(counts[:rank].sum())
+        total = int(counts.sum())
+        if self.ntotal + total >= MAX_GLOBAL_IDS:
+            raise RuntimeError("sharded index would hold %d rows: global ids must stay below 2^32-1" % (self.ntotal + total))
+        # route: sort this rank's vectors by owner (list % world), exchange the per-owner counts, then the payload
+        owner = labels % world
+        order = torch.argsort(owner, stable=True)
+        send_counts = torch.bincount(owner, minlength=world)
+        recv_counts = torch.empty_like(send_counts)
+        sc, rc = send_counts.to(dev), recv_counts.to(dev)
+        dist.all_to_all_single(rc, sc, group=group)
+        send_counts, recv_counts = send_counts.tolist(), rc.cpu().tolist()
+        meta = torch.stack([labels, torch.arange(id0, id0 + n, dtype=torch.int64)], dim=1)[order].contiguous().to(dev)
+        xs = x.to(dev)
+        if xs.dtype not in (torch.float32, torch.float16):
+            xs = xs.float()
+        xs = xs[order.to(xs.device)].contiguous()
+        nrecv = int(sum(recv_counts))
+        meta_r = torch.empty((nrecv, 2), dtype=torch.int64, device=dev)
+        x_r = torch.empty((nrecv, self.d), dtype=xs.dtype, device=dev)
+        dist.all_to_all_single(meta_r, meta, recv_counts, send_counts, group=group)
+        dist.all_to_all_single(x_r, xs, recv_counts, send_counts, group=group)
+        if nrecv:
+            meta_r = meta_r.cpu().numpy()
+            assert (meta_r[:, 0] % world == rank).all(), "routed add: received a member of a list this rank does not own"
+            self.local.add_preassigned(x_r, meta_r[:, 0].astype(np.int32), meta_r[:, 1])
+        self.ntotal += total
 
     def search(self, q, k: int):
-        if self.world == 1 or not dist.is_initialized():
+        if not self._collective() and not self._force_pipeline:
             return self.local.search(q, k)
-        if self._pipe is None:
-            self._pipe = _Pipeline(q.device)
-        return self._pipe.run(lambda qq, kk, out: self.local.search(qq, kk, out=out), self._merge, q, k, self.group)
+        return self._search(q, k, 0)

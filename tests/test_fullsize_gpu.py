@@ -27,8 +27,9 @@ def _basic_properties(D, I, ntotal):
         assert len(set(row.tolist())) == len(row), "duplicate ids in one result"
 
 
-def test_flat_1m_f32_batch1_configs1(ssa):
-    """BASELINE configs[1]: Flat IP 1M x 4096 fp32, batch 1 (K1) and a large batch (K2 on the fp16 shadow)."""
+def test_flat_1m_f32_batch1_configs1(ssa, monkeypatch):
+    """BASELINE configs[1]: Flat IP 1M x 4096 fp32, batch 1 (K1), a 64-query batch and the batch-1024 leg
+    (K2 on the fp16 shadow; recall@10 against the exact fp32 scan of the same queries)."""
     n, d, k = 1_000_000, 4096, 10
     index = ssa.IndexFlatIP(d)
     index.add_random_unit(n, seed=1234)
@@ -64,6 +65,27 @@ def test_flat_1m_f32_batch1_configs1(ssa):
     for qi in range(len(Q)):
         for j in np.nonzero(Im[qi] != I[qi])[0]:                      # an id may differ only at a score tie within 1e-3 rel
             assert abs(D[qi, j] - Dm[qi, j]) <= 1e-3 * abs(D[qi, j]) + 1e-4
+    # the batch-1024 leg of configs[1]: the 256-query MFMA kernel on the shadow, 4 query tiles
+    Q1k = np.concatenate([Q, unit_rows(1024 - len(Q), d, 777)])
+    Qt = torch.from_numpy(Q1k).cuda()
+    Dk, Ik = [t.cpu().numpy() for t in index.search(Qt, k)]
+    assert index.last_timing()["last_path"] == 1
+    _basic_properties(Dk, Ik, n)
+    np.testing.assert_array_equal(Ik[:len(planted), 0], planted)
+    Dk2, Ik2 = [t.cpu().numpy() for t in index.search(Qt, k)]
+    assert np.array_equal(Ik2, Ik) and np.array_equal(Dk2, Dk)        # idempotence
+    sel = np.arange(0, 1024, 8)                                       # 128 of the queries through the exact fp32 scan
+    monkeypatch.setenv("SSMI_NO_SHADOW", "1")
+    De, Ie = index.search(Q1k[sel], k)
+    assert index.last_timing()["last_path"] == 0
+    monkeypatch.delenv("SSMI_NO_SHADOW")
+    np.testing.assert_allclose(Dk[sel], De, rtol=1e-3, atol=1e-4)     # north-star score tolerance
+    recall = np.mean([len(set(a.tolist()) & set(b.tolist())) / k for a, b in zip(Ik[sel], Ie)])
+    assert recall >= 0.995, recall                                    # fp16 shadow + fp16 queries vs exact fp32: near-tie swaps only
+    for a, b, da, db in zip(Ik[sel], Ie, Dk[sel], De):
+        for j in np.nonzero(a != b)[0]:
+            assert abs(da[j] - db[j]) <= 1e-3 * abs(db[j]) + 1e-4
+    np.testing.assert_allclose(De, _rescored(index, Q1k[sel], De, Ie), rtol=1e-5, atol=2e-6)
     index.close()
 
 

@@ -50,3 +50,97 @@ def test_gathered_search_equals_direct(ssa, one_rank_group, B, k, pipelined):
         torch.cuda.synchronize()
         assert torch.equal(outs[i][1], Ir), f"step {i}: ids differ"
         assert torch.equal(outs[i][0], Dr), f"step {i}: scores differ"
+
+
+def test_routed_ivf_add_and_gathered_search_equal_plain_index(ssa, one_rank_group):
+    """ShardedIVFFlat on a one-rank RCCL group with the collectives forced on: broadcast centroids, routed add
+    (ssmi_index_assign -> all-to-all over RCCL -> ssmi_index_add_preassigned, device tensors end to end) and
+    the gathered search must give exactly what a plain IndexIVFFlat with the same centroids gives."""
+    from semantic_search_amd.sharded import ShardedIVFFlat
+    n, d, nlist, k = 30000, 512, 64, 10
+    X = torch.from_numpy(unit_rows(n, d, 7)).cuda()
+    sh = ShardedIVFFlat(d, nlist, storage="f16", device=0)
+    sh._force_pipeline = True
+    sh.train(X[:8192])
+    plain = ssa.IndexIVFFlat(ssa.IndexFlatIP(d, storage="f16"), d, nlist, ssa.METRIC_INNER_PRODUCT, storage="f16")
+    plain.set_centroids(sh.local.get_centroids())
+    for s0 in range(0, n, 7000):
+        sh.add_local(X[s0:s0 + 7000])
+        plain.add(X[s0:s0 + 7000])
+    assert sh.ntotal == n and sh.local.ntotal == n
+    np.testing.assert_array_equal(sh.local.list_sizes(), plain.list_sizes())
+    np.testing.assert_array_equal(sh.local.assignments(), plain.assignments())
+    Q = torch.from_numpy(unit_rows(40, d, 8)).cuda()
+    for nprobe, B in ((1, 1), (8, 1), (8, 40), (64, 3)):
+        sh.nprobe = plain.nprobe = nprobe
+        D, I = sh.search(Q[:B], k)
+        Dp, Ip = plain.search(Q[:B], k)
+        torch.cuda.synchronize()
+        assert torch.equal(I, Ip) and torch.equal(D, Dp), (nprobe, B)
+    with pytest.raises(ValueError):
+        sh.search(Q[:1].cpu(), k)                       # host queries cannot feed the device-side gather
+    with pytest.raises(RuntimeError):
+        sh.local.add_preassigned(X[:2], [0, nlist], [n, n + 1])   # list out of range: refused, nothing added
+    assert sh.local.ntotal == n
+
+
+def _rescored(index, Q, D, I, off):
+    out = np.zeros_like(D, dtype=np.float64)
+    for qi in range(Q.shape[0]):
+        rows = index.reconstruct_batch(I[qi] - off).astype(np.float64)
+        out[qi] = rows @ Q[qi].astype(np.float64)
+    return out
+
+
+def test_configs4_per_shard_shape_through_gather_and_merge(ssa, one_rank_group):
+    """BASELINE configs[4], one shard of it: 100M x 4096 fp16 rows over 8 GPUs = 12.5M rows (102.4 GB) per GPU.
+    The shard is searched through ShardedFlatIP's gather/merge path (RCCL all-gather of the packed (B,k)
+    results + ssmi_topk_merge) with a nonzero row offset, batch 1 (K1) and batch 4096 (K2), k=10.  Full-size
+    properties: planted rows (segment edges included) come back first under their GLOBAL ids, sortedness,
+    float64 re-scoring of the returned ids, sampled exactness, K1/K2 agreement."""
+    from semantic_search_amd.sharded import ShardedFlatIP
+    n, d, k = 12_500_000, 4096, 10
+    off = 3 * n                                           # rank 3's offset in the 100M-row database
+    idx = ShardedFlatIP(d, storage="f16", device=0)
+    idx.add_local_random_unit(n, seed=1234 + 3)
+    idx.finalize(device=torch.device("cuda", 0))
+    assert idx.ntotal == n
+    idx.row_offset = off
+    idx._force_pipeline = True
+    local = idx.local
+    planted = np.array([0, 131071, 131072, 6_250_000, n - 1], dtype=np.int64)
+    P = local.reconstruct_batch(planted)
+    Q = np.concatenate([P, unit_rows(3, d, 4321)])
+    Qd = torch.from_numpy(Q).cuda()
+    D = np.zeros((len(Q), k), np.float32); I = np.zeros((len(Q), k), np.int64)
+    for qi in range(len(Q)):                              # batch 1: K1 + merge tail, then gather + merge
+        a, b = idx.search(Qd[qi:qi + 1], k)
+        D[qi], I[qi] = a.cpu().numpy()[0], b.cpu().numpy()[0]
+    assert local.last_timing()["last_path"] == 0
+    assert (np.diff(D, axis=1) <= 0).all() and (I >= off).all() and (I < off + n).all()
+    np.testing.assert_array_equal(I[:len(planted), 0], planted + off)
+    np.testing.assert_allclose(D[:len(planted), 0], 1.0, atol=2e-3)
+    np.testing.assert_allclose(D, _rescored(local, Q, D, I, off), rtol=1e-5, atol=2e-6)
+    sample = np.random.default_rng(11).choice(n, 30_000, replace=False).astype(np.int64)
+    sc = local.reconstruct_batch(sample) @ Q.T
+    for qi in range(len(Q)):
+        better = sample[sc[:, qi] > D[qi, -1] * (1 + 1e-5) + 1e-6] + off
+        assert set(better.tolist()) <= set(I[qi].tolist()), f"query {qi}: a sampled row beats the k-th result"
+    # batch 4096 on the MFMA contraction through the same gather/merge path
+    Qb = torch.cat([Qd, torch.from_numpy(unit_rows(4096 - len(Q), d, 99)).cuda()])
+    Dm, Im = idx.search(Qb, k)
+    torch.cuda.synchronize()
+    assert local.last_timing()["last_path"] == 1
+    Dm, Im = Dm.cpu().numpy(), Im.cpu().numpy()
+    assert (np.diff(Dm, axis=1) <= 0).all() and (Im >= off).all() and (Im < off + n).all()
+    np.testing.assert_array_equal(Im[:len(planted), 0], planted + off)
+    np.testing.assert_allclose(Dm[:len(Q)], D, rtol=1e-3, atol=1e-4)
+    for qi in range(len(Q)):
+        for j in np.nonzero(Im[qi] != I[qi])[0]:          # an id may differ only at a score tie within 1e-3 rel
+            assert abs(D[qi, j] - Dm[qi, j]) <= 1e-3 * abs(D[qi, j]) + 1e-4
+    sel = np.array([100, 2000, 4095])
+    np.testing.assert_allclose(Dm[sel], _rescored(local, Qb[sel].cpu().numpy(), Dm[sel], Im[sel], off), rtol=1e-3, atol=1e-4)
+    Dm2, Im2 = idx.search(Qb, k)                          # idempotence
+    torch.cuda.synchronize()
+    assert np.array_equal(Im2.cpu().numpy(), Im) and np.array_equal(Dm2.cpu().numpy(), Dm)
+    local.close()
