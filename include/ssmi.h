@@ -178,6 +178,10 @@ int ssmi_index_get_timing(const ssmi_index* h, ssmi_timing* out);
 /* hipEvent durations (ms) of the dominant kernel (scan / contraction) of the last
  * min(max_n, 256) searches on this handle, oldest first (bench.py's roofline leg). */
 int ssmi_index_get_scan_times(const ssmi_index* h, int max_n, float* ms_out, int* n_out);
+/* name of the dominant kernel (scan / contraction) the last search on this handle launched: a static string
+ * owned by the library, "" before the first search (bench.py labels its roofline with it; rocprofv3 traces
+ * show the same name). */
+int ssmi_index_get_last_kernel(const ssmi_index* h, const char** out);
 /* Switches the per-search hipEvent triple on (default; env SSMI_TIMING=0 starts with it off) or off.
  * An event record between two kernels costs the stream about 6 us of idle time on this device, three
  * of them 12 % of a batch-1 IVF search, so a serving loop turns it off; get_timing then reports -1 ms

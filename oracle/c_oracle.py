@@ -14,14 +14,25 @@ def build():
     return _LIB
 
 
+_lib = None
+
+
 def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
     if not _LIB.exists():
         build()
     lib = ctypes.CDLL(str(_LIB))
+    _lib = lib
     lib.oracle_flat_ip_search.restype = ctypes.c_int
     lib.oracle_flat_ip_search.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
                                           ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     lib.oracle_num_threads.restype = ctypes.c_int
+    lib.oracle_ivf_flat_search.restype = ctypes.c_int
+    lib.oracle_ivf_flat_search.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     return lib
 
 
@@ -40,3 +51,31 @@ def search(X: np.ndarray, Q: np.ndarray, k: int):
     if rc:
         raise RuntimeError(f"oracle_flat_ip_search failed rc={rc}")
     return D, I
+
+
+class GroupedIVF:
+    """Rows grouped by list for oracle/ivf_flat.c: build once, search many times (the CPU IVF baseline)."""
+
+    def __init__(self, X: np.ndarray, C: np.ndarray, labels: np.ndarray, ids=None):
+        X = np.asarray(X, dtype=np.float32)
+        labels = np.asarray(labels, dtype=np.int64)
+        self.C = np.ascontiguousarray(C, dtype=np.float32)
+        nlist = self.C.shape[0]
+        order = np.argsort(labels, kind="stable")
+        self.Xs = np.ascontiguousarray(X[order])
+        self.ids = np.ascontiguousarray((np.arange(len(X), dtype=np.int64) if ids is None else np.asarray(ids, np.int64))[order])
+        self.off = np.zeros((nlist + 1,), np.int64)
+        np.cumsum(np.bincount(labels, minlength=nlist), out=self.off[1:])
+
+    def search(self, Q: np.ndarray, k: int, nprobe: int):
+        Q = np.ascontiguousarray(np.atleast_2d(np.asarray(Q, dtype=np.float32)))
+        nq, nlist, d = Q.shape[0], self.C.shape[0], self.C.shape[1]
+        nprobe = min(nprobe, nlist)
+        D = np.empty((nq, k), np.float32); I = np.empty((nq, k), np.int64)
+        P = np.empty((nq, nprobe), np.int64)
+        rc = _load().oracle_ivf_flat_search(self.C.ctypes.data, nlist, d, self.Xs.ctypes.data, self.ids.ctypes.data,
+                                            self.off.ctypes.data, Q.ctypes.data, nq, nprobe, k, D.ctypes.data,
+                                            I.ctypes.data, P.ctypes.data)
+        if rc:
+            raise RuntimeError(f"oracle_ivf_flat_search failed rc={rc}")
+        return D, I, P

@@ -4,15 +4,21 @@
 # three dominant kernels.  Raw output goes to gpurun_out/prof_<tag>_*; profiles/summarize.py
 # turns it into the small tracked summaries under profiles/.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 export TMPDIR=/tmp
 OUT=gpurun_out
-BENCH="python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-ivf-extra"  # the IVF side measurement launches the same scan kernel over the centroids: it would dilute the per-kernel averages
+# only the bench line itself: the side measurements launch the same kernels on other shapes (the exact-scan recall legs,
+# the IVF coarse quantizer) and would dilute the per-kernel averages.  The process prints its own ms_per_step and
+# roofline; summarize.py stores them next to the profiler's kernel average.
+BENCH="python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra"
+BENCH4K="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra --storage f16 --batch 4096"
 MFMA="python3 tools/prof_mfma.py 1000000 4096 4096 10"
 IVF="python3 tools/prof_ivf.py 2000000 4096 1024 16"
 
 echo "== kernel-trace stats: bench"
 timeout -s KILL 300 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/prof_${TAG}_stats -o bench -- $BENCH > $OUT/prof_${TAG}_stats.log 2>&1
+echo "== kernel-trace stats: bench, batch 4096 on f16 rows"
+timeout -s KILL 300 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/prof_${TAG}_b4096_stats -o bench -- $BENCH4K > $OUT/prof_${TAG}_b4096_stats.log 2>&1
 echo "== kernel-trace stats: ivf"
 timeout -s KILL 300 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/prof_${TAG}_ivf_stats -o ivf -- $IVF > $OUT/prof_${TAG}_ivf_stats.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do

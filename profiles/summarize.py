@@ -16,7 +16,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 GO = os.path.join(ROOT, "gpurun_out")
 
 
@@ -24,7 +24,18 @@ def short(name):
     return name.split("(")[0].strip()
 
 
-def stats(what, dirname):
+def bench_line(logname):
+    """The JSON line the profiled bench.py process printed (its own ms_per_step / roofline under the profiler)."""
+    try:
+        for line in open(os.path.join(GO, logname)):
+            if line.startswith("{") and '"metric"' in line:
+                return json.loads(line)
+    except Exception:
+        pass
+    return None
+
+
+def stats(what, dirname, logname=None, kernel=None, algo=None):
     files = glob.glob(os.path.join(GO, dirname, "**", "*kernel_stats.csv"), recursive=True)
     if not files:
         return
@@ -35,6 +46,30 @@ def stats(what, dirname):
         for r in rows[:13]:
             w.writerow([c[:160] for c in r])
     print("wrote", out)
+    line = bench_line(logname) if logname else None
+    if line and kernel:
+        # the profiled process's own numbers next to the profiler's average for the same kernel
+        hdr = rows[0]
+        avg_ns = None
+        for r in rows[1:]:
+            if kernel in r[hdr.index("Name")]:
+                avg_ns = float(r[hdr.index("AverageNs")])
+                break
+        roof = line["roofline"]
+        rec = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py ... (profiles/collect.sh)",
+               "workload": line["config"]["workload"], "kernel": kernel,
+               "profiled_process_ms_per_step": line["ms_per_step"],
+               "profiled_process_hipevent_kernel_avg_ms": roof["kernel_avg_ms"],
+               "profiled_process_roofline_frac": roof["frac"],
+               "rocprof_kernel_avg_ms": avg_ns / 1e6 if avg_ns else None}
+        if avg_ns:
+            work = roof.get("algorithmic_flops_per_launch") if roof["bound"] == "mfma" else roof["algorithmic_bytes_per_launch"]
+            scale = 1e12 if roof["bound"] == "mfma" else 1e9
+            rec["rocprof_roofline_frac"] = work / (avg_ns * 1e-9) / scale / roof["peak"]
+            rec["rocprof_vs_hipevent"] = avg_ns / 1e6 / roof["kernel_avg_ms"]
+        o2 = os.path.join(ROOT, "profiles", f"{tag}_{what}_vs_bench.json")
+        json.dump(rec, open(o2, "w"), indent=1)
+        print("wrote", o2)
 
 
 def counters(dirname):
@@ -75,11 +110,12 @@ def pmc(what, dirs, command, workload, keep):
     print("wrote", out)
 
 
-stats("bench", f"prof_{tag}_stats")
+stats("bench", f"prof_{tag}_stats", f"prof_{tag}_stats.log", "flat_scan_topk_kernel")
+stats("bench_b4096", f"prof_{tag}_b4096_stats", f"prof_{tag}_b4096_stats.log", "flat_mfma_pp_kernel")
 stats("ivf", f"prof_{tag}_ivf_stats")
 pmc("flat_f32_1M_b1", [f"prof_{tag}_pmc_FETCH_SIZE", f"prof_{tag}_pmc_WRITE_SIZE"],
-    "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate runs) -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline",
-    "Flat IP 1000000x4096 f32: batch 1 k=10 (flat_scan_topk_kernel) and the batch 1024/4096 side runs (flat_mfma_pp_kernel on the f16 shadow)",
+    "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate runs) -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra",
+    "Flat IP 1000000x4096 f32: batch 1 k=10 (flat_scan_topk_kernel)",
     ["flat_scan_topk_kernel", "flat_mfma_pp_kernel", "merge_keys_kernel"])
 pmc("mfma_f16_1M_b4096", [f"prof_{tag}_mfma_pmc_sq", f"prof_{tag}_mfma_pmc_lds", f"prof_{tag}_mfma_pmc_FETCH_SIZE"],
     "rocprofv3 --pmc <group> (separate runs) -- python3 tools/prof_mfma.py 1000000 4096 4096 10",

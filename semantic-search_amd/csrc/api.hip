@@ -374,6 +374,7 @@ static int store_search_mfma(ssmi_index* h, const RowStore& R, int64_t nq, const
     h->events_valid = h->timing_on;
     h->timing_valid = true;
     h->timing.last_path = 1;
+    h->last_kernel = p.kernel;
     h->timing.last_grid = p.grid;
     h->timing.last_scan_bytes = (int64_t)R.nrows * R.d * R.elsize;
     h->timing.last_scan_flops = 2ll * std::min<int64_t>(nq, kMaxBatch) * R.nrows * R.d;
@@ -447,6 +448,7 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
     h->events_valid = h->timing_on;
     h->timing_valid = true;
     h->timing.last_path = 0;
+    h->last_kernel = "flat_scan_topk_kernel";
     h->timing.last_grid = p.grid_x * p.grid_y;
     h->timing.last_scan_bytes = (int64_t)R.nrows * R.d * R.elsize * ((nq + p.bt - 1) / p.bt);
     h->timing.last_scan_flops = 2ll * nq * R.nrows * R.d;
@@ -574,6 +576,12 @@ int ssmi_index_get_timing(const ssmi_index* h, ssmi_timing* out) {
         t.last_scan_flops = 2 * rows * (int64_t)h->rows.d;
     }
     *out = t;
+    return 0;
+}
+
+int ssmi_index_get_last_kernel(const ssmi_index* h, const char** out) {
+    if (!h || !out) return fail("NULL argument");
+    *out = h->last_kernel;
     return 0;
 }
 

@@ -1043,6 +1043,8 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
     h->events_valid = h->timing_on;
     h->timing_valid = true;
     h->timing.last_path = 2;
+    h->last_kernel = list_major ? (list_mfma ? "ivf_scan_lists_mfma_kernel" : "ivf_scan_lists_kernel")
+                                : (qreg ? "ivf_scan_qreg_kernel" : "ivf_scan_topk_kernel");
     h->timing.last_grid = list_major ? -(list_mfma ? ivf_list_mfma_bt(std::min<int64_t>(nq, qbatch), nprobe, h->nlist) : lbt) : gx;  // negative: list-major scan with that many queries per work item
     h->timing.last_scan_bytes = -1;  // depends on the probed lists; see ssmi_index_get_list_sizes
     h->timing.last_scan_flops = -1;

@@ -29,6 +29,7 @@ struct MfmaPlan {
     bool narrow;  // <= 128 queries: the HBM-bound 128-query-tile stream (mfma_n128.hip)
     long long rows_per_slice;
     size_t qh_bytes, cand_bytes, lds;
+    const char* kernel;  // which contraction kernel launch_flat_mfma will run
 };
 bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_cu, MfmaPlan* p);
 // Q: (nq, ld) fp32 on device; qh/cand: workspaces of p.qh_bytes / p.cand_bytes; partial: [nq][p.nslices][k]

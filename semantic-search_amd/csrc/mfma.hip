@@ -60,6 +60,9 @@ bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_c
     p->cand_bytes = (size_t)p->grid * TN * CAND_CAP * sizeof(skey_t);
     const char* env_n = getenv("SSMI_MFMA_NARROW");
     p->narrow = nq <= N128_TN && !(env_n && env_n[0] == '0');
+    const char* env_r = getenv("SSMI_MFMA_R128");
+    p->kernel = !p->narrow ? "flat_mfma_pp_kernel"
+                : (mfma_r128_supported(ld, k) && !(env_r && env_r[0] == '0')) ? "flat_mfma_r128_kernel" : "flat_mfma_n128_kernel";
     p->lds = p->narrow ? (size_t)N128_RING * N128_SLOT + 3 * N128_TN * 4 + 16 : (size_t)4 * TILE_BYTES + EPI_LDS_BYTES;
     return true;
 }

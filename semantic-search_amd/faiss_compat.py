@@ -234,6 +234,12 @@ class _IndexBase:
         return {name: getattr(t, name) for name, _ in _lib.Timing._fields_}
 
 
+    def last_kernel(self) -> str:
+        """Name of the dominant kernel of the last search (as rocprofv3 shows it)."""
+        out = ctypes.c_char_p()
+        _lib.check(self._lib.ssmi_index_get_last_kernel(self._handle(), ctypes.byref(out)))
+        return (out.value or b"").decode()
+
     def set_timing(self, enabled: bool) -> None:
         """Per-search hipEvent records on (default) or off: each costs the stream ~6 us, so serving loops switch them off."""
         _lib.check(self._lib.ssmi_index_set_timing(self._handle(), 1 if enabled else 0))

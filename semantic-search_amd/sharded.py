@@ -281,12 +281,18 @@ class ShardedIVFFlat(_ShardedSearch):
         b = shard_bounds(n, self.world)
         self.add_local(x[b[self.rank]:b[self.rank + 1]])
 
-    def add_local(self, x) -> None:
+    def add_local(self, x, ids=None) -> None:
         """x: (n_r, d) vectors of THIS rank (numpy, CPU tensor or device tensor).  Global ids continue from
-        ntotal in rank order: rank r's vectors follow those of ranks < r."""
+        ntotal in rank order (rank r's vectors follow those of ranks < r) unless the caller names them
+        (`ids`, int64 (n_r,), unique across ranks: e.g. row offset + local row of a row-sharded twin)."""
+        if ids is not None:
+            ids = torch.as_tensor(np.asarray(ids.cpu() if isinstance(ids, torch.Tensor) else ids), dtype=torch.int64).reshape(-1)
+            if ids.shape[0] != int(x.shape[0]):
+                raise ValueError("add_local: one id per vector")
         if not self._collective():
             n = int(x.shape[0])
-            self.local.add_preassigned(x, self.local.assign(x), np.arange(self.ntotal, self.ntotal + n, dtype=np.int64))
+            own = np.arange(self.ntotal, self.ntotal + n, dtype=np.int64) if ids is None else ids.numpy()
+            self.local.add_preassigned(x, self.local.assign(x), own)
             self.ntotal += n
             return
         world, rank, group = self.world, self.rank, self.group
@@ -312,10 +318,13 @@ class ShardedIVFFlat(_ShardedSearch):
         sc, rc = send_counts.to(dev), recv_counts.to(dev)
         dist.all_to_all_single(rc, sc, group=group)
         send_counts, recv_counts = send_counts.tolist(), rc.cpu().tolist()
-        meta = torch.stack([labels, torch.arange(id0, id0 + n, dtype=torch.int64)], dim=1)[order].contiguous().to(dev)
+        own = torch.arange(id0, id0 + n, dtype=torch.int64) if ids is None else ids
+        meta = torch.stack([labels, own], dim=1)[order].contiguous().to(dev)
         xs = x.to(dev)
         if xs.dtype not in (torch.float32, torch.float16):
             xs = xs.float()
+        if getattr(self.local, "storage", "f32") == "f16":
+            xs = xs.half()  # what the owner stores anyway (same round-to-nearest-even): halves the bytes on the links
         xs = xs[order.to(xs.device)].contiguous()
         nrecv = int(sum(recv_counts))
         meta_r = torch.empty((nrecv, 2), dtype=torch.int64, device=dev)

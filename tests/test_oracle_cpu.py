@@ -42,6 +42,26 @@ def test_c_oracle_matches_numpy_oracle():
     assert ok, msg
 
 
+def test_c_ivf_oracle_matches_numpy_ivf_oracle():
+    """oracle/ivf_flat.c (the CPU IVF baseline of bench.py) against oracle/ivf_flat.py on the same centroids,
+    assignment and queries: probed lists, ids and scores; nprobe = nlist equals exact search; short results pad."""
+    from oracle import ivf_flat
+    n, d, nlist = 4000, 128, 32
+    X, Q = unit_rows(n, d, 5), unit_rows(7, d, 6)
+    C = unit_rows(nlist, d, 7)
+    labels = ivf_flat.assign(X, C)
+    g = c_oracle.GroupedIVF(X, C, labels)
+    for nprobe, k in ((1, 10), (5, 10), (5, 300), (nlist, 10)):
+        Dc, Ic, Pc = g.search(Q, k, nprobe)
+        D, I, P = ivf_flat.search(X, C, labels, Q, k, nprobe)
+        np.testing.assert_array_equal(Pc, P)
+        ok, msg, _ = flat_ip.check_against(Dc, Ic, D, I, X, Q, rtol=1e-5, tie_rtol=1e-5)
+        assert ok, (nprobe, k, msg)
+    D, I = flat_ip.search(X, Q, 10)
+    ok, msg, _ = flat_ip.check_against(Dc, Ic, D, I, X, Q, rtol=1e-5, tie_rtol=1e-5)
+    assert ok, msg
+
+
 def test_padding_and_tie_order():
     X = unit_rows(6, 32, 5)
     X[4] = X[1]
