@@ -178,6 +178,16 @@ int ssmi_index_get_timing(const ssmi_index* h, ssmi_timing* out);
 /* hipEvent durations (ms) of the dominant kernel (scan / contraction) of the last
  * min(max_n, 256) searches on this handle, oldest first (bench.py's roofline leg). */
 int ssmi_index_get_scan_times(const ssmi_index* h, int max_n, float* ms_out, int* n_out);
+/* The fp16 shadow (no reference counterpart).  Query batches of >= 9 over an fp32 index (Flat; IVF when the
+ * batch revisits lists) run on the matrix cores, which need fp16 operands: the first such search builds an fp16
+ * copy of the rows (+50 % HBM), later adds keep it in step, and those batches then carry fp16 rounding of rows
+ * and queries (scores within ~1e-4 relative, ids may swap at near-ties; batches of <= 8 stay exact).
+ * policy 1 (default): build it on demand; if it does not fit in HBM the search falls back to the exact fp32
+ * scan instead of failing.  policy 0: never - every batch stays exact; an existing shadow is freed.
+ * get_shadow_state: the policy, how many rows the shadow currently holds (0 = none), and whether the last
+ * attempt to build it ran out of memory. */
+int ssmi_index_set_shadow_policy(ssmi_index* h, int policy);
+int ssmi_index_get_shadow_state(const ssmi_index* h, int* policy, int64_t* shadow_rows, int* failed);
 /* name of the dominant kernel (scan / contraction) the last search on this handle launched: a static string
  * owned by the library, "" before the first search (bench.py labels its roofline with it; rocprofv3 traces
  * show the same name). */

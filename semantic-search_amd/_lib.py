@@ -77,6 +77,9 @@ _SIGNATURES = {
     "ssmi_index_read": [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_c_index_p)],
     "ssmi_index_get_timing": [_c_index_p, ctypes.POINTER(Timing)],
     "ssmi_index_get_scan_times": [_c_index_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)],
+    "ssmi_index_set_shadow_policy": [_c_index_p, ctypes.c_int],
+    "ssmi_index_get_shadow_state": [_c_index_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64),
+                                    ctypes.POINTER(ctypes.c_int)],
     "ssmi_index_get_last_kernel": [_c_index_p, ctypes.POINTER(ctypes.c_char_p)],
     "ssmi_index_set_timing": [_c_index_p, ctypes.c_int],
     "ssmi_index_get_list_sizes": [_c_index_p, ctypes.c_void_p],

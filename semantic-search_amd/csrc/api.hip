@@ -128,6 +128,24 @@ int ensure_ws(ssmi_index* h, int slot, size_t bytes) {
 }
 }  // namespace ssmi
 
+namespace ssmi {
+int order_search_on(ssmi_index* h, hipStream_t s) {
+    if (h->have_last_search && h->last_search_stream != s) {
+        // the previous search may still be running on its stream and owns the handle's workspaces until it ends
+        if (hipEventRecord(h->ev_order, h->last_search_stream) == hipSuccess) HIPCHECK(hipStreamWaitEvent(s, h->ev_order, 0));
+        else (void)hipGetLastError();  // that stream no longer exists: its work has drained
+    }
+    h->last_search_stream = s;
+    h->have_last_search = true;
+    return 0;
+}
+void quiesce(ssmi_index* h) {
+    if (h->have_last_search && h->last_search_stream != h->stream)
+        if (hipStreamSynchronize(h->last_search_stream) != hipSuccess) (void)hipGetLastError();
+    h->have_last_search = false;
+}
+}  // namespace ssmi
+
 static int create_common(int d, int storage_dtype, int device, int kind, ssmi_index** out) {
     if (!out) return fail("out is NULL");
     *out = nullptr;
@@ -154,6 +172,7 @@ static int create_common(int d, int storage_dtype, int device, int kind, ssmi_in
         return fail("libssmi is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
     CHECK(static_scratch_setup(device));  // ssmi_index_search_static's per-device scratch address
     HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming));
     for (int i = 0; i < ssmi_index::kEvRing; ++i)
         for (int j = 0; j < 3; ++j) HIPCHECK(hipEventCreate(&h->ev[i][j]));
     if (!getenv("SSMI_NO_TAIL")) {
@@ -198,19 +217,26 @@ extern "C" {
 const char* ssmi_last_error(void) { return g_err.c_str(); }
 int ssmi_abi_version(void) { return 1; }
 int ssmi_device_count(int* out) {
+    return guarded([&]() -> int {
     if (!out) return fail("out is NULL");
     HIPCHECK(hipGetDeviceCount(out));
     return 0;
+    });
 }
 
 int ssmi_index_create_flat(int d, int storage_dtype, int device, ssmi_index** out) {
+    return guarded([&]() -> int {
     return create_common(d, storage_dtype, device, SSMI_KIND_FLAT, out);
+    });
 }
 
 int ssmi_index_free(ssmi_index* h) {
+    return guarded([&]() -> int {
     if (!h) return 0;
     DeviceGuard g(h->device);
+    quiesce(h);
     (void)hipStreamSynchronize(h->stream);
+    if (h->ev_order) (void)hipEventDestroy(h->ev_order);
     ivf_destroy(h);
     h->rows.destroy();
     if (h->has_shadow) h->shadow16.destroy();
@@ -221,6 +247,7 @@ int ssmi_index_free(ssmi_index* h) {
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
+    });
 }
 
 #define GETTER(name, type, expr)                              \
@@ -237,23 +264,29 @@ GETTER(storage_dtype, int, h->rows.dtype)
 GETTER(device, int, h->device)
 
 int ssmi_index_get_nlist(const ssmi_index* h, int* out) {
+    return guarded([&]() -> int {
     if (!h || !out) return fail("NULL argument");
     if (h->kind != SSMI_KIND_IVFFLAT) return fail("nlist: not an IVF index");
     *out = h->nlist;
     return 0;
+    });
 }
 int ssmi_index_get_nprobe(const ssmi_index* h, int* out) {
+    return guarded([&]() -> int {
     if (!h || !out) return fail("NULL argument");
     if (h->kind != SSMI_KIND_IVFFLAT) return fail("nprobe: not an IVF index");
     *out = h->nprobe;
     return 0;
+    });
 }
 int ssmi_index_set_nprobe(ssmi_index* h, int nprobe) {
+    return guarded([&]() -> int {
     if (!h) return fail("NULL argument");
     if (h->kind != SSMI_KIND_IVFFLAT) return fail("nprobe: not an IVF index");
     if (nprobe < 1) return fail("nprobe must be >= 1");
     h->nprobe = nprobe;
     return 0;
+    });
 }
 
 // --------------------------------------------------------------------- add
@@ -303,6 +336,7 @@ int store_add(ssmi_index* h, RowStore& R, int64_t n, const void* x, int src_dtyp
 extern "C" {
 
 int ssmi_index_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind) {
+    return guarded([&]() -> int {
     if (!h) return fail("NULL index");
     if (n < 0) return fail("negative n");
     if (n == 0) return 0;
@@ -310,15 +344,20 @@ int ssmi_index_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int m
     if (src_dtype != SSMI_F32 && src_dtype != SSMI_F16) return fail("unknown source dtype %d", src_dtype);
     if (mem_kind != SSMI_HOST && mem_kind != SSMI_DEVICE) return fail("unknown mem_kind %d", mem_kind);
     DeviceGuard g(h->device);
+    quiesce(h);
+    h->shadow_failed = false;
     if (h->kind == SSMI_KIND_FLAT) return store_add(h, h->rows, n, x, src_dtype, mem_kind);
     return ivf_add(h, n, x, src_dtype, mem_kind);
+    });
 }
 
 int ssmi_index_add_random_unit(ssmi_index* h, int64_t n, uint64_t seed) {
+    return guarded([&]() -> int {
     if (!h) return fail("NULL index");
     if (n < 0) return fail("negative n");
     if (n == 0) return 0;
     DeviceGuard g(h->device);
+    quiesce(h);
     if (h->kind != SSMI_KIND_FLAT) return ivf_add_random_unit(h, n, seed);
     RowStore& R = h->rows;
     const long long row0 = R.nrows;
@@ -328,13 +367,17 @@ int ssmi_index_add_random_unit(ssmi_index* h, int64_t n, uint64_t seed) {
     HIPCHECK(hipStreamSynchronize(h->stream));
     R.nrows = row0 + n;
     return 0;
+    });
 }
 
 int ssmi_index_train(ssmi_index* h, int64_t n, const float* x, int mem_kind) {
+    return guarded([&]() -> int {
     if (!h) return fail("NULL index");
     if (h->kind == SSMI_KIND_FLAT) return 0;  // IndexFlatIP.train is a no-op
     DeviceGuard g(h->device);
+    quiesce(h);
     return ivf_train(h, n, x, mem_kind);
+    });
 }
 
 // ------------------------------------------------------------------ search
@@ -391,16 +434,24 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
     if (R.dtype == SSMI_F16 && (R.ld % 64) == 0 && nq >= mfma_min_batch(SSMI_F16))
         return store_search_mfma(h, R, nq, qdev, k, Ddev, Idev, id_offset, s, record);
     if (&R == &h->rows && h->kind == SSMI_KIND_FLAT && R.dtype == SSMI_F32 && (R.ld % 64) == 0 &&
-        nq >= mfma_min_batch(SSMI_F32) && !getenv("SSMI_NO_SHADOW")) {
-        // bring the fp16 shadow up to date, then run the MFMA contraction on it
-        if (!h->has_shadow) { CHECK(h->shadow16.init(R.d, SSMI_F16)); h->has_shadow = true; }
-        RowStore& S = h->shadow16;
-        if (S.nrows < R.nrows) {
-            CHECK(S.reserve(R.nrows, s));
-            HIPCHECK(launch_shadow_rows(R.view(), (void* const*)S.d_segs, S.seg_shift, S.nrows, R.nrows - S.nrows, s));
-            S.nrows = R.nrows;
-        }
-        return store_search_mfma(h, S, nq, qdev, k, Ddev, Idev, id_offset, s, record);
+        nq >= mfma_min_batch(SSMI_F32) && h->shadow_policy != 0 && !h->shadow_failed && !getenv("SSMI_NO_SHADOW")) {
+        // bring the fp16 shadow up to date, then run the MFMA contraction on it.  A shadow that does not fit in
+        // HBM is not an error of the search: it is dropped and this and later batches stay on the exact scan.
+        auto bring_up = [&]() -> int {
+            if (!h->has_shadow) { CHECK(h->shadow16.init(R.d, SSMI_F16)); h->has_shadow = true; }
+            RowStore& S = h->shadow16;
+            if (S.nrows < R.nrows) {
+                CHECK(S.reserve(R.nrows, s));
+                HIPCHECK(launch_shadow_rows(R.view(), (void* const*)S.d_segs, S.seg_shift, S.nrows, R.nrows - S.nrows, s));
+                S.nrows = R.nrows;
+            }
+            return 0;
+        };
+        if (bring_up() == 0) return store_search_mfma(h, h->shadow16, nq, qdev, k, Ddev, Idev, id_offset, s, record);
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(s);
+        if (h->has_shadow) { h->shadow16.destroy(); h->has_shadow = false; }
+        h->shadow_failed = true;
     }
     ScanPlan p;
     std::string err;
@@ -459,6 +510,7 @@ extern "C" {
 
 int ssmi_index_search(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind, int k, float* D, int64_t* I,
                       int out_mem_kind, int64_t id_offset, void* stream) {
+    return guarded([&]() -> int {
     if (!h) return fail("NULL index");
     if (nq < 0) return fail("negative nq");
     if (nq == 0) return 0;
@@ -474,6 +526,7 @@ int ssmi_index_search(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind,
     const bool any_dev = q_mem_kind == SSMI_DEVICE || out_mem_kind == SSMI_DEVICE;
     hipStream_t s = (stream || any_dev) ? (hipStream_t)stream : h->stream;
     if (h->kind == SSMI_KIND_IVFFLAT && !h->trained) return fail("search on an untrained IVF index");
+    CHECK(order_search_on(h, s));
 
     float* Ddev = D;
     int64_t* Idev = I;
@@ -498,10 +551,12 @@ int ssmi_index_search(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind,
         HIPCHECK(hipStreamSynchronize(s));
     }
     return 0;
+    });
 }
 
 int ssmi_topk_merge(int device, int nlists, int64_t nq, int k, const float* D_lists, int64_t d_list_stride,
                     const int64_t* I_lists, int64_t i_list_stride, float* D_out, int64_t* I_out, void* stream) {
+    return guarded([&]() -> int {
     if (nlists < 1 || nq < 0 || k < 1) return fail("bad merge shape");
     if (k > kMaxK) return fail("k=%d exceeds the supported maximum %d", k, kMaxK);
     if (nq == 0) return 0;
@@ -512,15 +567,18 @@ int ssmi_topk_merge(int device, int nlists, int64_t nq, int k, const float* D_li
     HIPCHECK(launch_merge_lists(D_lists, d_list_stride, I_lists, i_list_stride, nlists, (int)nq, k, D_out, I_out,
                                 (hipStream_t)stream));
     return 0;
+    });
 }
 
 // ------------------------------------------------------------- reconstruct
 int ssmi_index_reconstruct_n(ssmi_index* h, int64_t n, const int64_t* ids, float* out_host) {
+    return guarded([&]() -> int {
     if (!h) return fail("NULL index");
     if (n < 0) return fail("negative n");
     if (n == 0) return 0;
     if (!ids || !out_host) return fail("NULL buffer");
     DeviceGuard g(h->device);
+    quiesce(h);
     const RowStore& R = h->rows;
     const int64_t ntotal = h->kind == SSMI_KIND_FLAT ? R.nrows : h->ivf_ntotal;
     for (int64_t i = 0; i < n; ++i)
@@ -548,10 +606,12 @@ int ssmi_index_reconstruct_n(ssmi_index* h, int64_t n, const int64_t* ids, float
         HIPCHECK(hipStreamSynchronize(h->stream));
     }
     return 0;
+    });
 }
 
 // ----------------------------------------------------------------- timing
 int ssmi_index_get_timing(const ssmi_index* h, ssmi_timing* out) {
+    return guarded([&]() -> int {
     if (!h || !out) return fail("NULL argument");
     if (!h->timing_valid) return fail("no search has run on this index");
     DeviceGuard g(h->device);
@@ -577,22 +637,53 @@ int ssmi_index_get_timing(const ssmi_index* h, ssmi_timing* out) {
     }
     *out = t;
     return 0;
+    });
+}
+
+int ssmi_index_set_shadow_policy(ssmi_index* h, int policy) {
+    return guarded([&]() -> int {
+    if (!h) return fail("NULL index");
+    if (policy != 0 && policy != 1) return fail("shadow policy must be 0 (never) or 1 (on demand)");
+    DeviceGuard g(h->device);
+    quiesce(h);
+    h->shadow_policy = policy;
+    h->shadow_failed = false;
+    if (policy == 0 && h->has_shadow) {  // give the memory back
+        HIPCHECK(hipDeviceSynchronize());
+        h->shadow16.destroy();
+        h->has_shadow = false;
+    }
+    return 0;
+    });
+}
+
+int ssmi_index_get_shadow_state(const ssmi_index* h, int* policy, int64_t* shadow_rows, int* failed) {
+    if (!h || !policy || !shadow_rows || !failed) return fail("NULL argument");
+    *policy = h->shadow_policy;
+    *shadow_rows = h->has_shadow ? h->shadow16.nrows : 0;
+    *failed = h->shadow_failed ? 1 : 0;
+    return 0;
 }
 
 int ssmi_index_get_last_kernel(const ssmi_index* h, const char** out) {
+    return guarded([&]() -> int {
     if (!h || !out) return fail("NULL argument");
     *out = h->last_kernel;
     return 0;
+    });
 }
 
 int ssmi_index_set_timing(ssmi_index* h, int enabled) {
+    return guarded([&]() -> int {
     if (!h) return fail("NULL index");
     h->timing_on = enabled != 0;
     return 0;
+    });
 }
 
 // durations (ms) of the dominant kernel of the last `max_n` searches, oldest first
 int ssmi_index_get_scan_times(const ssmi_index* h, int max_n, float* ms_out, int* n_out) {
+    return guarded([&]() -> int {
     if (!h || !ms_out || !n_out) return fail("NULL argument");
     DeviceGuard g(h->device);
     long long n = std::min<long long>(std::min<long long>(max_n, h->n_searches), ssmi_index::kEvRing);
@@ -603,6 +694,7 @@ int ssmi_index_get_scan_times(const ssmi_index* h, int max_n, float* ms_out, int
     }
     *n_out = (int)n;
     return 0;
+    });
 }
 
 }  // extern "C"

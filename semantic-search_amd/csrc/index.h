@@ -2,6 +2,8 @@
 #pragma once
 #include "../../include/ssmi.h"
 #include "common.h"
+#include <exception>
+#include <new>
 #include <vector>
 #include <string>
 
@@ -40,7 +42,18 @@ struct ssmi_index {
     // it can run on the MFMA kernel (costs +50 % HBM; batch-1..8 searches keep using the fp32 rows)
     ssmi::RowStore shadow16;
     bool has_shadow = false;
+    // 1 (default): large batches over fp32 rows may build and use the shadow; 0: never (every batch stays on the
+    // exact fp32 scan).  ssmi_index_set_shadow_policy; env SSMI_NO_SHADOW=1 overrides to 0.
+    int shadow_policy = 1;
+    bool shadow_failed = false;  // the shadow did not fit in HBM: searches fell back to the exact scan (reset by add)
     hipStream_t stream = nullptr;
+    // Searches with device buffers return after ENQUEUEING on the caller's stream, while the workspaces, the IVF
+    // page tables and the ticket counters belong to the handle.  The handle therefore remembers the stream of
+    // its last search: a search on another stream is ordered behind it (one event, recorded only at the
+    // switch), and every call that changes shared state first waits for it (quiesce).
+    hipStream_t last_search_stream = nullptr;
+    bool have_last_search = false;
+    hipEvent_t ev_order = nullptr;
     // ring of (scan start, scan stop, merge stop) event triples, one per search call
     static const int kEvRing = 256;
     hipEvent_t ev[kEvRing][3] = {};
@@ -75,6 +88,22 @@ struct ssmi_index {
         int rc__ = (expr); \
         if (rc__) return rc__; \
     } while (0)
+
+// Every extern "C" body runs inside guarded(): a C++ exception (std::bad_alloc from a corrupt size field, a
+// std::length_error, ...) must not cross the C boundary - ctypes would see std::terminate and the process abort,
+// where faiss.read_index & co. raise a Python exception.  It becomes an error code + message instead.
+template <typename F>
+inline int guarded(F&& f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return ssmi::fail("out of host memory");
+    } catch (const std::exception& e) {
+        return ssmi::fail("%s", e.what());
+    } catch (...) {
+        return ssmi::fail("unknown C++ exception");
+    }
+}
 
 struct DeviceGuard {
     int prev = -1;
@@ -112,6 +141,10 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
 
 // static_search.hip: resolves this device's copy of the static scratch array (once per device, device current)
 int static_scratch_setup(int device);
+
+// stream ordering of the calls on one handle (see ssmi_index::last_search_stream)
+int order_search_on(ssmi_index* h, hipStream_t s);
+void quiesce(ssmi_index* h);
 
 // IVF entry points (ivf.hip)
 int ivf_create(ssmi_index* h, int nlist);

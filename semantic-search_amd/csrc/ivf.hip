@@ -882,17 +882,27 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
     const char* env_lmm = getenv("SSMI_IVF_LIST_MFMA");  // 0: keep the register-FMA form
     // fp32 lists run the matrix-core scan on an fp16 shadow of the slot store (same policy as Flat: batches on
     // fp32 storage trade exact fp32 products for the MFMA path; +50 % HBM; SSMI_NO_SHADOW=1 keeps them exact)
-    const bool via_shadow = list_major && R.dtype == SSMI_F32 && !getenv("SSMI_NO_SHADOW") &&
-                            ivf_list_mfma_supported(SSMI_F16, R.ld, k) && !(env_lmm && env_lmm[0] == '0');
-    const bool list_mfma = via_shadow || (list_major && ivf_list_mfma_supported(R.dtype, R.ld, k) && !(env_lmm && env_lmm[0] == '0'));
+    bool via_shadow = list_major && R.dtype == SSMI_F32 && h->shadow_policy != 0 && !h->shadow_failed && !getenv("SSMI_NO_SHADOW") &&
+                      ivf_list_mfma_supported(SSMI_F16, R.ld, k) && !(env_lmm && env_lmm[0] == '0');
     if (via_shadow && !h->has_shadow) {
-        CHECK(h->shadow16.init(R.d, SSMI_F16));
-        h->has_shadow = true;
-        CHECK(h->shadow16.reserve(R.nrows, s));
-        RowView src = R.view();
-        HIPCHECK(launch_shadow_rows(src, (void* const*)h->shadow16.d_segs, h->shadow16.seg_shift, 0, R.nrows, s));
-        h->shadow16.nrows = R.nrows;
+        auto bring_up = [&]() -> int {
+            CHECK(h->shadow16.init(R.d, SSMI_F16));
+            h->has_shadow = true;
+            CHECK(h->shadow16.reserve(R.nrows, s));
+            RowView src = R.view();
+            HIPCHECK(launch_shadow_rows(src, (void* const*)h->shadow16.d_segs, h->shadow16.seg_shift, 0, R.nrows, s));
+            h->shadow16.nrows = R.nrows;
+            return 0;
+        };
+        if (bring_up()) {  // no room for the shadow: not an error of the search, the exact register-FMA scan takes over
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(s);
+            if (h->has_shadow) { h->shadow16.destroy(); h->has_shadow = false; }
+            h->shadow_failed = true;
+            via_shadow = false;
+        }
     }
+    const bool list_mfma = via_shadow || (list_major && ivf_list_mfma_supported(R.dtype, R.ld, k) && !(env_lmm && env_lmm[0] == '0'));
     const size_t per_q = list_major ? (size_t)nprobe * k * sizeof(skey_t) : (size_t)gx * k * sizeof(skey_t);
     const int64_t qbatch = std::max<int64_t>(1, std::min<int64_t>(nq, ((size_t)256 << 20) / per_q));
     for (int64_t done = 0; done < nq; done += qbatch) {
@@ -1067,6 +1077,7 @@ int ivf_ids_to_slots(ssmi_index* h, int64_t n, const int64_t* ids, std::vector<i
 extern "C" {
 
 int ssmi_index_create_ivfflat(int d, int nlist, int storage_dtype, int device, ssmi_index** out) {
+    return guarded([&]() -> int {
     if (!out) return fail("out is NULL");
     *out = nullptr;
     if (nlist < 1) return fail("nlist must be >= 1");
@@ -1077,17 +1088,22 @@ int ssmi_index_create_ivfflat(int d, int nlist, int storage_dtype, int device, s
     if (ivf_create(h, nlist)) { ssmi_index_free(h); return 1; }
     *out = h;
     return 0;
+    });
 }
 
 int ssmi_index_set_centroids(ssmi_index* h, const float* centroids, int mem_kind) {
+    return guarded([&]() -> int {
     if (!h || !centroids) return fail("NULL argument");
     if (h->kind != SSMI_KIND_IVFFLAT) return fail("set_centroids: not an IVF index");
     if (h->ivf_ntotal != 0) return fail("set_centroids: index already holds vectors");
     DeviceGuard g(h->device);
+    quiesce(h);
     return install_centroids(h, centroids, mem_kind);
+    });
 }
 
 int ssmi_index_get_centroids(const ssmi_index* hc, float* out_host) {
+    return guarded([&]() -> int {
     ssmi_index* h = const_cast<ssmi_index*>(hc);
     if (!h || !out_host) return fail("NULL argument");
     if (h->kind != SSMI_KIND_IVFFLAT) return fail("get_centroids: not an IVF index");
@@ -1103,9 +1119,11 @@ int ssmi_index_get_centroids(const ssmi_index* hc, float* out_host) {
         r += cnt;
     }
     return 0;
+    });
 }
 
 int ssmi_index_make_direct_map(ssmi_index* h) {
+    return guarded([&]() -> int {
     if (!h) return fail("NULL argument");
     if (h->kind != SSMI_KIND_IVFFLAT) return 0;  // flat rows are their own direct map
     DeviceGuard g(h->device);
@@ -1123,10 +1141,12 @@ int ssmi_index_make_direct_map(ssmi_index* h) {
         }
     S->has_direct_map = true;
     return 0;
+    });
 }
 
 int ssmi_index_add_ivf_shard(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind, int64_t id0,
                              int shard, int nshards) {
+    return guarded([&]() -> int {
     if (!h) return fail("NULL index");
     if (h->kind != SSMI_KIND_IVFFLAT) return fail("add_ivf_shard: not an IVF index");
     if (n < 0) return fail("negative n");
@@ -1135,10 +1155,13 @@ int ssmi_index_add_ivf_shard(ssmi_index* h, int64_t n, const void* x, int src_dt
     if (src_dtype != SSMI_F32 && src_dtype != SSMI_F16) return fail("unknown source dtype %d", src_dtype);
     if (mem_kind != SSMI_HOST && mem_kind != SSMI_DEVICE) return fail("unknown mem_kind %d", mem_kind);
     DeviceGuard g(h->device);
+    quiesce(h);
     return ivf_add_shard(h, n, x, src_dtype, mem_kind, id0, shard, nshards);
+    });
 }
 
 int ssmi_index_assign(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind, int32_t* labels_out_host) {
+    return guarded([&]() -> int {
     if (!h) return fail("NULL index");
     if (h->kind != SSMI_KIND_IVFFLAT) return fail("assign: not an IVF index");
     if (!h->trained) return fail("assign on an untrained IVF index (call train first)");
@@ -1148,6 +1171,7 @@ int ssmi_index_assign(ssmi_index* h, int64_t n, const void* x, int src_dtype, in
     if (src_dtype != SSMI_F32 && src_dtype != SSMI_F16) return fail("unknown source dtype %d", src_dtype);
     if (mem_kind != SSMI_HOST && mem_kind != SSMI_DEVICE) return fail("unknown mem_kind %d", mem_kind);
     DeviceGuard g(h->device);
+    quiesce(h);
     const RowStore& R = h->rows;
     const size_t el = src_dtype == SSMI_F32 ? 4 : 2;
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(1 << 16, ((size_t)1 << 30) / ((size_t)R.ld * 4)));
@@ -1160,10 +1184,12 @@ int ssmi_index_assign(ssmi_index* h, int64_t n, const void* x, int src_dtype, in
         std::copy(labels.begin(), labels.end(), labels_out_host + done);
     }
     return 0;
+    });
 }
 
 int ssmi_index_add_preassigned(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind,
                                const int32_t* labels_host, const int64_t* ids_host) {
+    return guarded([&]() -> int {
     if (!h) return fail("NULL index");
     if (h->kind != SSMI_KIND_IVFFLAT) return fail("add_preassigned: not an IVF index");
     if (!h->trained) return fail("add on an untrained IVF index (call train first)");
@@ -1182,6 +1208,7 @@ int ssmi_index_add_preassigned(ssmi_index* h, int64_t n, const void* x, int src_
         ids32[(size_t)i] = (uint32_t)ids_host[i];
     }
     DeviceGuard g(h->device);
+    quiesce(h);
     const RowStore& R = h->rows;
     const size_t el = src_dtype == SSMI_F32 ? 4 : 2;
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(1 << 16, ((size_t)1 << 30) / ((size_t)R.ld * 4)));
@@ -1192,16 +1219,20 @@ int ssmi_index_add_preassigned(ssmi_index* h, int64_t n, const void* x, int src_
         CHECK(ivf_append_preassigned(h, cnt, xdev, labels_host + done, ids32.data() + done, nullptr));
     }
     return 0;
+    });
 }
 
 int ssmi_index_get_list_sizes(const ssmi_index* h, int64_t* out_host) {
+    return guarded([&]() -> int {
     if (!h || !out_host) return fail("NULL argument");
     if (h->kind != SSMI_KIND_IVFFLAT) return fail("get_list_sizes: not an IVF index");
     for (int l = 0; l < h->nlist; ++l) out_host[l] = st(h)->size[l];
     return 0;
+    });
 }
 
 int ssmi_index_get_assignments(const ssmi_index* hc, int32_t* out_host) {
+    return guarded([&]() -> int {
     ssmi_index* h = const_cast<ssmi_index*>(hc);
     if (!h || !out_host) return fail("NULL argument");
     if (h->kind != SSMI_KIND_IVFFLAT) return fail("get_assignments: not an IVF index");
@@ -1217,6 +1248,7 @@ int ssmi_index_get_assignments(const ssmi_index* hc, int32_t* out_host) {
             out_host[id] = l;
         }
     return 0;
+    });
 }
 
 }  // extern "C"

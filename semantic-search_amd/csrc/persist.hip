@@ -89,8 +89,10 @@ int write_flat_payload(ssmi_index* h, const RowStore& R, long long nrows, FILE* 
 extern "C" {
 
 int ssmi_index_write(ssmi_index* h, const char* path) {
+    return guarded([&]() -> int {
     if (!h || !path) return fail("NULL argument");
     DeviceGuard g(h->device);
+    quiesce(h);
     File F;
     F.f = fopen(path, "wb");
     if (!F.f) return fail("write_index: cannot open %s for writing", path);
@@ -130,6 +132,7 @@ int ssmi_index_write(ssmi_index* h, const char* path) {
     }
     if (fflush(f) != 0) return fail("write_index: flush failed for %s", path);
     return 0;
+    });
 }
 
 // Checkpoint of a growing Flat index: when `path` already holds an earlier state of THIS index (same d, a
@@ -138,9 +141,11 @@ int ssmi_index_write(ssmi_index* h, const char* path) {
 // Anything else (no file, another index, an IVF index) is a full rewrite.  The reference rewrites the whole file
 // at every checkpoint (core/index_manager.py:859-860 -> :241): N*d*4 bytes each time.
 int ssmi_index_write_append(ssmi_index* h, const char* path) {
+    return guarded([&]() -> int {
     if (!h || !path) return fail("NULL argument");
     if (h->kind != SSMI_KIND_FLAT) return ssmi_index_write(h, path);
     DeviceGuard g(h->device);
+    quiesce(h);
     const RowStore& R = h->rows;
     const long kHeader = 4 + 33;  // fourcc + header; then n_floats:u64, then the rows
     int64_t have = -1;
@@ -188,6 +193,7 @@ int ssmi_index_write_append(ssmi_index* h, const char* path) {
         !wr1<uint64_t>(f, (uint64_t)R.nrows * (uint64_t)R.d) || fflush(f) != 0)
         return fail("write_index: header update failed for %s", path);
     return 0;
+    });
 }
 
 // reads "IxFI" + header + payload into an existing empty flat-like store via store_add
@@ -201,6 +207,13 @@ static int read_flat_into(ssmi_index* h, RowStore& R, FILE* f, int expect_d, int
     uint64_t nfl;
     if (!rd1(f, &nfl)) return fail("read_index: truncated file");
     if (nfl != (uint64_t)nt * (uint64_t)d) return fail("read_index: payload size %llu != ntotal*d", (unsigned long long)nfl);
+    {
+        const long here = ftell(f);
+        if (here < 0 || fseek(f, 0, SEEK_END) != 0) return fail("read_index: seek failed");
+        const long end = ftell(f);
+        if (fseek(f, here, SEEK_SET) != 0) return fail("read_index: seek failed");
+        if (end < here || (uint64_t)(end - here) / 4 < nfl) return fail("read_index: truncated vector payload (%llu floats claimed, %llu bytes left)", (unsigned long long)nfl, (unsigned long long)(end - here));
+    }
     const int64_t chunk = std::max<int64_t>(1, ((size_t)64 << 20) / ((size_t)d * 4));
     std::vector<float> buf((size_t)std::min<int64_t>(chunk, std::max<int64_t>(nt, 1)) * d);
     for (int64_t done = 0; done < nt; done += chunk) {
@@ -213,6 +226,7 @@ static int read_flat_into(ssmi_index* h, RowStore& R, FILE* f, int expect_d, int
 }
 
 int ssmi_index_read(const char* path, int storage_dtype, int device, ssmi_index** out) {
+    return guarded([&]() -> int {
     if (!path || !out) return fail("NULL argument");
     *out = nullptr;
     if (storage_dtype < 0) storage_dtype = SSMI_F32;
@@ -261,7 +275,7 @@ int ssmi_index_read(const char* path, int storage_dtype, int device, ssmi_index*
     uint8_t dm_type; uint64_t dm_n;
     if (!rd1(f, &dm_type) || !rd1(f, &dm_n)) return fail("read_index: truncated direct map");
     if (dm_type > 1) return fail("read_index: hashtable direct maps are not supported");
-    if (fseek(f, (long)(dm_n * 8), SEEK_CUR) != 0) return fail("read_index: seek failed");
+    if (dm_n > ((uint64_t)1 << 40) || fseek(f, (long)(dm_n * 8), SEEK_CUR) != 0) return fail("read_index: corrupt direct map");
     uint64_t il_nlist, code_size, nsz;
     if (!rd(f, cc, 4) || memcmp(cc, "ilar", 4) != 0) return fail("read_index: unsupported inverted-list type '%.4s'", cc);
     if (!rd1(f, &il_nlist) || !rd1(f, &code_size) || il_nlist != nlist || code_size != (uint64_t)d * 4)
@@ -271,7 +285,7 @@ int ssmi_index_read(const char* path, int storage_dtype, int device, ssmi_index*
     if (memcmp(cc, "full", 4) == 0) {
         if (!rd1(f, &nsz) || nsz != nlist || !rd(f, sizes.data(), (size_t)nlist * 8)) return fail("read_index: corrupt list sizes");
     } else if (memcmp(cc, "sprs", 4) == 0) {
-        if (!rd1(f, &nsz) || (nsz & 1)) return fail("read_index: corrupt sparse list sizes");
+        if (!rd1(f, &nsz) || (nsz & 1) || nsz > 2 * nlist) return fail("read_index: corrupt sparse list sizes");
         std::vector<uint64_t> pairs((size_t)nsz);
         if (!rd(f, pairs.data(), (size_t)nsz * 8)) return fail("read_index: corrupt sparse list sizes");
         for (size_t i = 0; i + 1 < pairs.size(); i += 2) {
@@ -281,30 +295,52 @@ int ssmi_index_read(const char* path, int storage_dtype, int device, ssmi_index*
     } else {
         return fail("read_index: unknown list-size encoding '%.4s'", cc);
     }
+    // nothing is allocated from a size field before the sizes have been checked against the header and against the
+    // bytes the file still holds (a corrupt or truncated file must fail with a message, not with bad_alloc)
+    const long list_start = ftell(f);
+    if (list_start < 0 || fseek(f, 0, SEEK_END) != 0) return fail("read_index: seek failed");
+    const long file_end = ftell(f);
+    if (file_end < list_start || fseek(f, list_start, SEEK_SET) != 0) return fail("read_index: seek failed");
+    const uint64_t bytes_left = (uint64_t)(file_end - list_start);
+    const uint64_t rec = (uint64_t)d * 4 + 8;  // one member: its code and its id
+    uint64_t members = 0;
+    for (uint64_t l = 0; l < nlist; ++l) {
+        if (sizes[(size_t)l] > bytes_left / rec) return fail("read_index: list %llu claims %llu vectors, more than the file holds", (unsigned long long)l, (unsigned long long)sizes[(size_t)l]);
+        members += sizes[(size_t)l];
+    }
+    if (members != (uint64_t)ntotal) return fail("read_index: lists hold %llu vectors, header says %lld", (unsigned long long)members, (long long)ntotal);
+    if (members * rec > bytes_left) return fail("read_index: truncated inverted lists (%llu bytes needed, %llu left)", (unsigned long long)(members * rec), (unsigned long long)bytes_left);
+    // each list is read in bounded chunks: codes of the chunk, then (seek) its ids, so host memory stays at ~64 MiB
+    const int64_t chunk = std::max<int64_t>(1, ((size_t)64 << 20) / ((size_t)d * 4));
     std::vector<float> buf; std::vector<int64_t> ids64; std::vector<uint32_t> ids32; std::vector<int> labels;
     int64_t got = 0;
+    long pos = list_start;
     for (uint64_t l = 0; l < nlist; ++l) {
         const int64_t n = (int64_t)sizes[(size_t)l];
         if (n == 0) continue;
-        buf.resize((size_t)n * d); ids64.resize((size_t)n); ids32.resize((size_t)n); labels.assign((size_t)n, (int)l);
-        if (!rd(f, buf.data(), (size_t)n * d * 4) || !rd(f, ids64.data(), (size_t)n * 8)) return fail("read_index: truncated inverted list %llu", (unsigned long long)l);
-        for (int64_t i = 0; i < n; ++i) {
-            if (ids64[i] < 0 || ids64[i] >= 0xFFFFFFFFll) return fail("read_index: id %lld out of the supported range", (long long)ids64[i]);
-            ids32[i] = (uint32_t)ids64[i];
-        }
-        const int64_t chunk = std::max<int64_t>(1, ((size_t)256 << 20) / ((size_t)d * 4));
+        const long codes0 = pos, ids0 = pos + (long)((uint64_t)n * d * 4);
         for (int64_t done = 0; done < n; done += chunk) {
             const int64_t cnt = std::min(chunk, n - done);
+            buf.resize((size_t)cnt * d); ids64.resize((size_t)cnt); ids32.resize((size_t)cnt); labels.assign((size_t)cnt, (int)l);
+            if (fseek(f, codes0 + (long)((uint64_t)done * d * 4), SEEK_SET) != 0 || !rd(f, buf.data(), (size_t)cnt * d * 4) ||
+                fseek(f, ids0 + (long)((uint64_t)done * 8), SEEK_SET) != 0 || !rd(f, ids64.data(), (size_t)cnt * 8))
+                return fail("read_index: truncated inverted list %llu", (unsigned long long)l);
+            for (int64_t i = 0; i < cnt; ++i) {
+                if (ids64[i] < 0 || ids64[i] >= 0xFFFFFFFFll) return fail("read_index: id %lld out of the supported range", (long long)ids64[i]);
+                ids32[i] = (uint32_t)ids64[i];
+            }
             const float* xdev = nullptr;
-            CHECK(rows_to_device_f32(h, cnt, buf.data() + (size_t)done * d, SSMI_F32, SSMI_HOST, &xdev));
-            CHECK(ivf_append_preassigned(h, cnt, xdev, labels.data() + done, ids32.data() + done));
+            CHECK(rows_to_device_f32(h, cnt, buf.data(), SSMI_F32, SSMI_HOST, &xdev));
+            CHECK(ivf_append_preassigned(h, cnt, xdev, labels.data(), ids32.data()));
         }
+        pos = ids0 + (long)((uint64_t)n * 8);
         got += n;
     }
     if (got != ntotal) return fail("read_index: lists hold %lld vectors, header says %lld", (long long)got, (long long)ntotal);
     guard.h = nullptr;
     *out = h;
     return 0;
+    });
 }
 
 }  // extern "C"

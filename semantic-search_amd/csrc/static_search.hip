@@ -51,13 +51,16 @@ int static_scratch_setup(int device) {
 extern "C" {
 
 int ssmi_static_scratch_bytes(size_t* out) {
+    return guarded([&]() -> int {
     if (!out) return fail("out is NULL");
     *out = (size_t)SSMI_STATIC_SCRATCH_BYTES;
     return 0;
+    });
 }
 
 int ssmi_index_search_static(ssmi_index* h, int64_t nq, const float* q_dev, int k, float* D_dev, int64_t* I_dev,
                              int64_t id_offset, void* stream) {
+    return guarded([&]() -> int {
     if (!h) return fail("NULL index");
     if (h->kind != SSMI_KIND_FLAT) return fail("search_static: Flat indexes only");
     if (nq < 0) return fail("negative nq");
@@ -102,6 +105,7 @@ int ssmi_index_search_static(ssmi_index* h, int64_t nq, const float* q_dev, int 
     if (R.dtype == SSMI_F32) HIPCHECK(launch_flat_scan_f32(R.view(), q_dev, (int)nq, k, partial, p, s));
     else HIPCHECK(launch_flat_scan_f16(R.view(), q_dev, (int)nq, k, partial, p, s));
     return 0;
+    });
 }
 
 }  // extern "C"

@@ -234,6 +234,32 @@ class _IndexBase:
         return {name: getattr(t, name) for name, _ in _lib.Timing._fields_}
 
 
+    # -- fp16 shadow of fp32 rows (large batches on the matrix cores) ---------
+    def _shadow_state(self):
+        pol, rows, failed = ctypes.c_int(), ctypes.c_int64(), ctypes.c_int()
+        _lib.check(self._lib.ssmi_index_get_shadow_state(self._handle(), ctypes.byref(pol), ctypes.byref(rows), ctypes.byref(failed)))
+        return int(pol.value), int(rows.value), bool(failed.value)
+
+    @property
+    def fp16_shadow(self) -> bool:
+        """True (default): batches of >= 9 queries over fp32 rows may build an fp16 copy of the rows (+50 % HBM) and
+        run on the matrix cores with fp16-rounded operands.  False: every batch stays on the exact fp32 scan."""
+        return self._shadow_state()[0] != 0
+
+    @fp16_shadow.setter
+    def fp16_shadow(self, enabled: bool) -> None:
+        _lib.check(self._lib.ssmi_index_set_shadow_policy(self._handle(), 1 if enabled else 0))
+
+    @property
+    def fp16_shadow_rows(self) -> int:
+        """Rows the shadow holds right now (0: not built)."""
+        return self._shadow_state()[1]
+
+    @property
+    def fp16_shadow_failed(self) -> bool:
+        """The last attempt to build the shadow ran out of HBM; searches fell back to the exact scan."""
+        return self._shadow_state()[2]
+
     def last_kernel(self) -> str:
         """Name of the dominant kernel of the last search (as rocprofv3 shows it)."""
         out = ctypes.c_char_p()
@@ -255,7 +281,7 @@ class _IndexBase:
 class IndexFlatIP(_IndexBase):
     """Exact maximum-inner-product index (stand-in for faiss.IndexFlatIP)."""
 
-    def __init__(self, d: int, storage: str = "f32", device: Optional[int] = None, _handle=None):
+    def __init__(self, d: int, storage: str = "f32", device: Optional[int] = None, fp16_shadow: bool = True, _handle=None):
         super().__init__()
         if _handle is not None:
             self._h = _handle
@@ -264,6 +290,8 @@ class IndexFlatIP(_IndexBase):
         h = ctypes.c_void_p()
         _lib.check(self._lib.ssmi_index_create_flat(int(d), _STORAGE[storage], dev, ctypes.byref(h)))
         self._h = h
+        if not fp16_shadow:
+            self.fp16_shadow = False
 
 
 class IndexIVFFlat(_IndexBase):
@@ -271,7 +299,7 @@ class IndexIVFFlat(_IndexBase):
     (stand-in for faiss.IndexIVFFlat with METRIC_INNER_PRODUCT)."""
 
     def __init__(self, quantizer, d: int, nlist: int, metric: int = METRIC_INNER_PRODUCT, storage: str = "f32",
-                 device: Optional[int] = None, _handle=None):
+                 device: Optional[int] = None, fp16_shadow: bool = True, _handle=None):
         super().__init__()
         self.quantizer = quantizer
         if _handle is not None:
@@ -287,6 +315,8 @@ class IndexIVFFlat(_IndexBase):
         _lib.check(self._lib.ssmi_index_create_ivfflat(int(d), int(nlist), _STORAGE[storage], int(device),
                                                        ctypes.byref(h)))
         self._h = h
+        if not fp16_shadow:
+            self.fp16_shadow = False
 
     @property
     def nlist(self) -> int:

@@ -70,7 +70,7 @@ class IndexConfig:
 INDEX_TYPE_DESCRIPTIONS = {
     IndexType.FLAT: {
         "name": "Flat (Exact)",
-        "description": "Exact search on the GPU, 100% accurate. HBM-bandwidth bound; fine up to tens of millions of vectors per MI355X.",
+        "description": "Exact search on the GPU (every vector is scored). Batches of up to 8 queries use exact fp32 products; larger batches run on the matrix cores with fp16-rounded operands (scores within ~1e-4, near-ties may swap; set index.fp16_shadow = False to keep them exact). HBM-bandwidth bound; fine up to tens of millions of vectors per MI355X.",
         "needs_training": False,
         "supports_removal": False,
     },

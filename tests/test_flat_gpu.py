@@ -70,6 +70,40 @@ def test_flat_f32_large_batch_exact_path_without_shadow(ssa, monkeypatch):
     assert index.last_timing()["last_path"] == 0
 
 
+def test_fp16_shadow_is_visible_and_can_be_switched_off(ssa):
+    """The shadow is not a silent mode: the handle reports it, recall of the shadow path against the exact path is
+    measured on oracle-checked data, and fp16_shadow=False keeps every batch on the exact fp32 scan (bit-identical
+    to the per-query results)."""
+    X, Q = unit_rows(20000, 1024, 1234), unit_rows(64, 1024, 4321)
+    index = ssa.IndexFlatIP(1024)
+    index.add(X)
+    assert index.fp16_shadow and index.fp16_shadow_rows == 0 and not index.fp16_shadow_failed
+    Dr, Ir = flat_ip.search(X, Q, 10)
+    Ds, Is = index.search(Q, 10)                      # 64 queries: MFMA on the shadow
+    assert index.last_timing()["last_path"] == 1 and index.fp16_shadow_rows == 20000
+    assert index.last_kernel().startswith("flat_mfma_")
+    recall = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(Is, Ir)])
+    assert recall >= 0.995, recall
+    ok, msg, _ = flat_ip.check_against(Ds, Is, Dr, Ir, X, Q, rtol=1e-3, tie_rtol=1e-3, atol=2e-5)
+    assert ok, msg
+    index.add(X[:100])                                # the shadow follows adds at the next batched search
+    index.search(Q, 10)
+    assert index.fp16_shadow_rows == 20100
+    index.fp16_shadow = False                         # frees the copy; batches are exact from here on
+    assert not index.fp16_shadow and index.fp16_shadow_rows == 0
+    De, Ie = index.search(Q, 10)
+    assert index.last_timing()["last_path"] == 0 and index.last_kernel() == "flat_scan_topk_kernel"
+    for i in (0, 17, 63):                             # search(Q)[i] == search(Q[i:i+1])
+        D1, I1 = index.search(Q[i:i + 1], 10)
+        np.testing.assert_array_equal(I1[0], Ie[i]); np.testing.assert_array_equal(D1[0], De[i])
+    exact = ssa.IndexFlatIP(1024, fp16_shadow=False)
+    exact.add(X)
+    D2, I2 = exact.search(Q, 10)
+    assert exact.last_timing()["last_path"] == 0
+    ok, msg, _ = flat_ip.check_against(D2, I2, Dr, Ir, X, Q, rtol=RTOL, tie_rtol=RTOL)
+    assert ok, msg
+
+
 @pytest.mark.parametrize("n,d,nq,k", [(10000, 4096, 1, 10), (10000, 4096, 4, 10), (3000, 4096, 2, 100),
                                       (2000, 2048, 1, 10), (777, 72, 3, 10), (5000, 72, 8, 10)])
 def test_flat_f16_storage_matches_oracle_on_rounded_rows(ssa, n, d, nq, k):
@@ -216,6 +250,32 @@ def test_large_random_unit_matches_oracle_on_readback(ssa):
     assert np.allclose(np.linalg.norm(X, axis=1), 1.0, atol=1e-4)
     assert abs(float(X.mean())) < 1e-3 and abs(float(X.std()) * np.sqrt(d) - 1.0) < 0.02
     _check(index, X, unit_rows(2, d, 4321), 10)
+
+
+def test_one_handle_searched_from_two_streams_and_adds_in_between(ssa):
+    """Device-buffer searches return after enqueueing while the handle's workspaces are shared: searches issued
+    from two streams are ordered behind one another by the library, and an add waits for the searches in flight
+    (it rewrites buffers they read).  Results must equal the serial ones."""
+    import torch
+    d, k = 4096, 10
+    X = unit_rows(60000, d, 51)
+    index = ssa.IndexFlatIP(d)
+    index.add(X[:50000])
+    Q = torch.from_numpy(unit_rows(24, d, 52)).cuda()
+    want = [index.search(Q[i:i + 1], k) for i in range(24)]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for i in range(24):
+        with torch.cuda.stream(s1 if i % 2 == 0 else s2):
+            outs.append(index.search(Q[i:i + 1], k))
+    index.add(X[50000:])                       # while the last searches may still be running
+    torch.cuda.synchronize()
+    for i in range(24):
+        assert torch.equal(outs[i][1], want[i][1]) and torch.equal(outs[i][0], want[i][0]), i
+    assert index.ntotal == 60000
+    D, I = index.search(X[59999], 1)
+    assert I[0, 0] == 59999
 
 
 def test_distinct_indexes_from_distinct_threads(ssa):

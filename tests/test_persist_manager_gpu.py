@@ -77,6 +77,19 @@ def test_read_independently_written_ivf_file(ssa, tmp_path):
     (tmp_path / "bad.faiss").write_bytes(b"IHNf" + b"\0" * 64)
     with pytest.raises(RuntimeError, match="unsupported index type"):
         ssa.read_index(tmp_path / "bad.faiss")
+    # corrupt or truncated files fail with a message (faiss.read_index raises; nothing may abort the process):
+    # a list size of 2^60, sizes that do not add up to ntotal, a file cut inside a list, a flat payload count of 2^62
+    sizes_at = buf.index(b"full") + 4 + 8
+    for name, data in (
+            ("huge_list", buf[:sizes_at] + struct.pack("<Q", 1 << 60) + buf[sizes_at + 8:]),
+            ("bad_sum", buf[:sizes_at] + struct.pack("<Q", int((labels == 0).sum()) + 1) + buf[sizes_at + 8:]),
+            ("cut", buf[:-100]),
+            ("cut_in_sizes", buf[:sizes_at + 12]),
+            ("flat_huge", b"IxFI" + faiss_header(d, 1 << 50) + struct.pack("<Q", (1 << 50) * d) + X.tobytes()),
+            ("flat_cut", b"IxFI" + faiss_header(d, n) + struct.pack("<Q", n * d) + X.tobytes()[:-4])):
+        (tmp_path / name).write_bytes(data)
+        with pytest.raises(RuntimeError, match="read_index"):
+            ssa.read_index(tmp_path / name)
 
 
 def test_factory_rebuild_and_compact_on_device(ssa):
