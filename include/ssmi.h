@@ -120,6 +120,15 @@ int ssmi_index_search(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind,
                       int k, float* D, int64_t* I, int out_mem_kind,
                       int64_t id_offset, void* stream);
 
+/* ssmi_index_search with a score floor: only results with score >= min_score are reported (the rest of a row is
+ * padded with -1 / -FLT_MAX like any short result).  This is the search nodes' min_score filter
+ * (nodes/search_nodes.py:152-159: `[r for r in results if r.score >= min_score]`) applied inside the kernels: the
+ * scans start their top-k thresholds at the floor instead of at "anything goes" and the merge cuts what is
+ * left below it, so no host pass over the results is needed.  min_score <= -FLT_MAX
+ * means no floor; ssmi_index_search is this call with no floor. */
+int ssmi_index_search_min(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind, int k, float min_score, float* D,
+                          int64_t* I, int out_mem_kind, int64_t id_offset, void* stream);
+
 /* Allocation-free variant of ssmi_index_search.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
  * cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc).  Flat indexes whose dimension is a multiple of 8; q, D, I are DEVICE buffers; work is enqueued on
@@ -151,6 +160,14 @@ int ssmi_topk_merge(int device, int nlists, int64_t nq, int k,
  * out: (n,d) fp32 host.  IVF handles need ssmi_index_make_direct_map first,
  * otherwise this fails like FAISS does without a direct map. */
 int ssmi_index_reconstruct_n(ssmi_index* h, int64_t n, const int64_t* ids, float* out_host);
+/* the same with the rows delivered into DEVICE memory ((n,d) fp32 on the index's GPU; the call returns when
+ * they are there): rebuild_index / compact_index (core/index_factory.py:273-274,371-372) move an index into a
+ * new one chunk by chunk without a host copy of the vectors. */
+int ssmi_index_reconstruct_n_dev(ssmi_index* h, int64_t n, const int64_t* ids, float* out_dev);
+/* replaces the per-candidate reconstruct + np.dot of the exclusion search (core/index_manager.py:604-621):
+ * out_host[i*n_neg + j] = <stored vector ids[i], neg[j]>, fp32 products of the rows as stored, computed on the
+ * device (one launch for all candidates and negatives).  ids, neg (n_neg,d) fp32 and out are host buffers. */
+int ssmi_index_score_ids(ssmi_index* h, int64_t n, const int64_t* ids, int n_neg, const float* neg_host, float* out_host);
 int ssmi_index_make_direct_map(ssmi_index* h);
 
 /* ---- persistence -------------------------------------------------------- */

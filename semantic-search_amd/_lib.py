@@ -65,12 +65,16 @@ _SIGNATURES = {
     "ssmi_index_add_random_unit": [_c_index_p, ctypes.c_int64, ctypes.c_uint64],
     "ssmi_index_search": [_c_index_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                           ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p],
+    "ssmi_index_search_min": [_c_index_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p],
     "ssmi_index_search_static": [_c_index_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p],
     "ssmi_static_scratch_bytes": [ctypes.POINTER(ctypes.c_size_t)],
     "ssmi_topk_merge": [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
                         ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
     "ssmi_index_reconstruct_n": [_c_index_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p],
+    "ssmi_index_reconstruct_n_dev": [_c_index_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p],
+    "ssmi_index_score_ids": [_c_index_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p],
     "ssmi_index_make_direct_map": [_c_index_p],
     "ssmi_index_write": [_c_index_p, ctypes.c_char_p],
     "ssmi_index_write_append": [_c_index_p, ctypes.c_char_p],

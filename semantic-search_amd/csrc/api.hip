@@ -391,7 +391,7 @@ static int mfma_min_batch(int dtype) {
 }
 
 static int store_search_mfma(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev, int k, float* Ddev,
-                             int64_t* Idev, int64_t id_offset, hipStream_t s, bool record) {
+                             int64_t* Idev, int64_t id_offset, hipStream_t s, bool record, unsigned min_ord) {
     // 16 query tiles -> 16 database slices on 256 CUs.  A small store (an IVF coarse quantizer: add and k-means
     // assign 65536 vectors at a time) is walked whole by every workgroup instead: one pass with 256 query
     // tiles, not 16 passes of one row tile per workgroup
@@ -406,10 +406,10 @@ static int store_search_mfma(ssmi_index* h, const RowStore& R, int64_t nq, const
         CHECK(ensure_ws(h, 2, (size_t)nb * p.nslices * k * sizeof(skey_t)));
         skey_t* partial = (skey_t*)h->ws[2];
         if (record && h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[0], s));
-        HIPCHECK(launch_flat_mfma(R.view(), qdev + (size_t)done * R.ld, nb, k, p, h->ws[4], h->ws[5], partial, s));
+        HIPCHECK(launch_flat_mfma(R.view(), qdev + (size_t)done * R.ld, nb, k, p, h->ws[4], h->ws[5], partial, s, min_ord));
         if (record && h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[1], s));
         HIPCHECK(launch_merge_keys(partial, nb, p.nslices, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
-                                   id_offset, s));
+                                   id_offset, s, min_ord));
         if (record && h->timing_on && done == 0) { HIPCHECK(hipEventRecord(ev[2], s)); h->merge_event = true; }
     }
     if (!record) return 0;
@@ -430,9 +430,9 @@ namespace ssmi {
 // for small batches, K2 (MFMA) for large batches over fp16 rows; K3 merges.
 // record = false: no events/timing (used for the IVF coarse quantizer).
 int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev /*(nq,ld)*/, int k, float* Ddev,
-                 int64_t* Idev, int64_t id_offset, hipStream_t s, bool record, ProbePlanRequest* plan) {
+                 int64_t* Idev, int64_t id_offset, hipStream_t s, bool record, ProbePlanRequest* plan, unsigned min_ord) {
     if (R.dtype == SSMI_F16 && (R.ld % 64) == 0 && nq >= mfma_min_batch(SSMI_F16))
-        return store_search_mfma(h, R, nq, qdev, k, Ddev, Idev, id_offset, s, record);
+        return store_search_mfma(h, R, nq, qdev, k, Ddev, Idev, id_offset, s, record, min_ord);
     if (&R == &h->rows && h->kind == SSMI_KIND_FLAT && R.dtype == SSMI_F32 && (R.ld % 64) == 0 &&
         nq >= mfma_min_batch(SSMI_F32) && h->shadow_policy != 0 && !h->shadow_failed && !getenv("SSMI_NO_SHADOW")) {
         // bring the fp16 shadow up to date, then run the MFMA contraction on it.  A shadow that does not fit in
@@ -447,7 +447,7 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
             }
             return 0;
         };
-        if (bring_up() == 0) return store_search_mfma(h, h->shadow16, nq, qdev, k, Ddev, Idev, id_offset, s, record);
+        if (bring_up() == 0) return store_search_mfma(h, h->shadow16, nq, qdev, k, Ddev, Idev, id_offset, s, record, min_ord);
         (void)hipGetLastError();
         (void)hipStreamSynchronize(s);
         if (h->has_shadow) { h->shadow16.destroy(); h->has_shadow = false; }
@@ -473,7 +473,7 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
         // the scan merges its own per-block lists when a ticket counter per query tile is at hand
         const bool tail = h->tail_counters && p.grid_y <= ssmi_index::kTailCounters;
         p.tail = TailMerge{tail ? h->tail_counters : nullptr, Ddev + (size_t)done * k, Idev + (size_t)done * k, id_offset,
-                           nullptr, nullptr, nullptr, nullptr};
+                           nullptr, nullptr, nullptr, nullptr, min_ord};
         if (tail && plan && p.r == 1 && done == 0 && nb == nq) {  // IVF coarse quantizer: K7 rides along
             p.tail.plan_sizes = plan->sizes;
             p.tail.plan_prefix = plan->prefix;
@@ -488,7 +488,7 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
         if (rec) HIPCHECK(hipEventRecord(ev[1], s));
         if (!tail)
             HIPCHECK(launch_merge_keys(partial, (int)nb, p.grid_x, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
-                                       id_offset, s));
+                                       id_offset, s, min_ord));
         if (rec && !tail) HIPCHECK(hipEventRecord(ev[2], s));  // with a merge tail there is nothing between ev[1] and ev[2]
         if (rec) h->merge_event = !tail;
         first = false;
@@ -508,8 +508,8 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
 }  // namespace ssmi
 extern "C" {
 
-int ssmi_index_search(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind, int k, float* D, int64_t* I,
-                      int out_mem_kind, int64_t id_offset, void* stream) {
+int ssmi_index_search_min(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind, int k, float min_score, float* D,
+                          int64_t* I, int out_mem_kind, int64_t id_offset, void* stream) {
     return guarded([&]() -> int {
     if (!h) return fail("NULL index");
     if (nq < 0) return fail("negative nq");
@@ -518,6 +518,9 @@ int ssmi_index_search(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind,
     if (k < 1) return fail("k must be >= 1");
     if (k > kMaxK) return fail("k=%d exceeds the supported maximum %d", k, kMaxK);
     if (nq > (1ll << 24)) return fail("nq too large");
+    if (min_score != min_score) return fail("min_score is NaN");
+    // f32_to_ord(min_score); -FLT_MAX or below (incl. -inf) = no floor, encoded as 0
+    const unsigned min_ord = min_score <= SSMI_NEG_MAX ? 0u : f32_to_ord(min_score);
     if (q_mem_kind != SSMI_HOST && q_mem_kind != SSMI_DEVICE) return fail("unknown q_mem_kind %d", q_mem_kind);
     if (out_mem_kind != SSMI_HOST && out_mem_kind != SSMI_DEVICE) return fail("unknown out_mem_kind %d", out_mem_kind);
     DeviceGuard g(h->device);
@@ -542,8 +545,8 @@ int ssmi_index_search(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind,
     } else {
         const float* qdev = nullptr;
         CHECK(stage_queries(h, nq, q, q_mem_kind, s, &qdev));
-        if (h->kind == SSMI_KIND_FLAT) CHECK(store_search(h, h->rows, nq, qdev, k, Ddev, Idev, id_offset, s, true));
-        else CHECK(ivf_search(h, nq, qdev, k, Ddev, Idev, id_offset, s));
+        if (h->kind == SSMI_KIND_FLAT) CHECK(store_search(h, h->rows, nq, qdev, k, Ddev, Idev, id_offset, s, true, nullptr, min_ord));
+        else CHECK(ivf_search(h, nq, qdev, k, Ddev, Idev, id_offset, s, min_ord));
     }
     if (out_mem_kind == SSMI_HOST) {
         HIPCHECK(hipMemcpyAsync(D, Ddev, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
@@ -552,6 +555,11 @@ int ssmi_index_search(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind,
     }
     return 0;
     });
+}
+
+int ssmi_index_search(ssmi_index* h, int64_t nq, const float* q, int q_mem_kind, int k, float* D, int64_t* I,
+                      int out_mem_kind, int64_t id_offset, void* stream) {
+    return ssmi_index_search_min(h, nq, q, q_mem_kind, k, SSMI_NEG_MAX, D, I, out_mem_kind, id_offset, stream);
 }
 
 int ssmi_topk_merge(int device, int nlists, int64_t nq, int k, const float* D_lists, int64_t d_list_stride,
@@ -571,6 +579,48 @@ int ssmi_topk_merge(int device, int nlists, int64_t nq, int k, const float* D_li
 }
 
 // ------------------------------------------------------------- reconstruct
+}  // extern "C" (reopened below)
+namespace {
+// ids (host) -> row numbers of h->rows (identity for Flat, the direct map for IVF), validated
+int resolve_rows(ssmi_index* h, int64_t n, const int64_t* ids, std::vector<int64_t>* slots, const int64_t** rows) {
+    const int64_t ntotal = h->kind == SSMI_KIND_FLAT ? h->rows.nrows : h->ivf_ntotal;
+    for (int64_t i = 0; i < n; ++i)
+        if (ids[i] < 0 || ids[i] >= ntotal) return fail("reconstruct: id %lld out of range [0, %lld)", (long long)ids[i], (long long)ntotal);
+    *rows = ids;
+    if (h->kind == SSMI_KIND_IVFFLAT) {
+        CHECK(ivf_ids_to_slots(h, n, ids, slots));
+        *rows = slots->data();
+    }
+    return 0;
+}
+// rows by id -> (n, d) fp32, to a host buffer (staged through the workspace) or straight into a device buffer
+int gather_by_ids(ssmi_index* h, int64_t n, const int64_t* ids, float* out, bool out_on_device) {
+    const RowStore& R = h->rows;
+    std::vector<int64_t> slots;
+    const int64_t* src_ids = nullptr;
+    CHECK(resolve_rows(h, n, ids, &slots, &src_ids));
+    const int64_t chunk = std::max<int64_t>(1, ((size_t)64 << 20) / ((size_t)R.d * 4));
+    for (int64_t done = 0; done < n; done += chunk) {
+        const int64_t cnt = std::min(chunk, n - done);
+        const size_t ids_bytes = ((size_t)cnt * 8 + 255) / 256 * 256;
+        CHECK(ensure_ws(h, 0, ids_bytes + 256 + (out_on_device ? 0 : (size_t)cnt * R.d * 4)));
+        int64_t* dids = (int64_t*)h->ws[0];
+        int* bad = (int*)((char*)h->ws[0] + ids_bytes);
+        float* dout = out_on_device ? out + (size_t)done * R.d : (float*)((char*)h->ws[0] + ids_bytes + 256);
+        HIPCHECK(hipMemcpyAsync(dids, src_ids + done, (size_t)cnt * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(hipMemsetAsync(bad, 0, 4, h->stream));
+        RowView v = R.view();
+        if (h->kind == SSMI_KIND_IVFFLAT) v.nrows = h->ivf_slots_used;
+        HIPCHECK(launch_gather_rows(v, R.dtype, dids, cnt, R.d, dout, bad, h->stream));
+        if (!out_on_device)
+            HIPCHECK(hipMemcpyAsync(out + (size_t)done * R.d, dout, (size_t)cnt * R.d * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+}  // namespace
+extern "C" {
+
 int ssmi_index_reconstruct_n(ssmi_index* h, int64_t n, const int64_t* ids, float* out_host) {
     return guarded([&]() -> int {
     if (!h) return fail("NULL index");
@@ -579,32 +629,50 @@ int ssmi_index_reconstruct_n(ssmi_index* h, int64_t n, const int64_t* ids, float
     if (!ids || !out_host) return fail("NULL buffer");
     DeviceGuard g(h->device);
     quiesce(h);
+    return gather_by_ids(h, n, ids, out_host, false);
+    });
+}
+
+int ssmi_index_reconstruct_n_dev(ssmi_index* h, int64_t n, const int64_t* ids, float* out_dev) {
+    return guarded([&]() -> int {
+    if (!h) return fail("NULL index");
+    if (n < 0) return fail("negative n");
+    if (n == 0) return 0;
+    if (!ids || !out_dev) return fail("NULL buffer");
+    DeviceGuard g(h->device);
+    quiesce(h);
+    return gather_by_ids(h, n, ids, out_dev, true);
+    });
+}
+
+int ssmi_index_score_ids(ssmi_index* h, int64_t n, const int64_t* ids, int n_neg, const float* neg_host, float* out_host) {
+    return guarded([&]() -> int {
+    if (!h) return fail("NULL index");
+    if (n < 0 || n_neg < 0) return fail("negative count");
+    if (n == 0 || n_neg == 0) return 0;
+    if (!ids || !neg_host || !out_host) return fail("NULL buffer");
+    if (n > (1ll << 24) || n_neg > 4096) return fail("score_ids: too many candidates or negatives");
+    DeviceGuard g(h->device);
+    quiesce(h);
     const RowStore& R = h->rows;
-    const int64_t ntotal = h->kind == SSMI_KIND_FLAT ? R.nrows : h->ivf_ntotal;
-    for (int64_t i = 0; i < n; ++i)
-        if (ids[i] < 0 || ids[i] >= ntotal) return fail("reconstruct: id %lld out of range [0, %lld)", (long long)ids[i], (long long)ntotal);
     std::vector<int64_t> slots;
-    const int64_t* src_ids = ids;
-    if (h->kind == SSMI_KIND_IVFFLAT) {
-        CHECK(ivf_ids_to_slots(h, n, ids, &slots));
-        src_ids = slots.data();
-    }
-    const int64_t chunk = std::max<int64_t>(1, ((size_t)64 << 20) / ((size_t)R.d * 4));
-    for (int64_t done = 0; done < n; done += chunk) {
-        const int64_t cnt = std::min(chunk, n - done);
-        const size_t ids_bytes = ((size_t)cnt * 8 + 255) / 256 * 256;
-        CHECK(ensure_ws(h, 0, ids_bytes + 256 + (size_t)cnt * R.d * 4));
-        int64_t* dids = (int64_t*)h->ws[0];
-        int* bad = (int*)((char*)h->ws[0] + ids_bytes);
-        float* dout = (float*)((char*)h->ws[0] + ids_bytes + 256);
-        HIPCHECK(hipMemcpyAsync(dids, src_ids + done, (size_t)cnt * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(hipMemsetAsync(bad, 0, 4, h->stream));
-        RowView v = R.view();
-        if (h->kind == SSMI_KIND_IVFFLAT) v.nrows = h->ivf_slots_used;
-        HIPCHECK(launch_gather_rows(v, R.dtype, dids, cnt, R.d, dout, bad, h->stream));
-        HIPCHECK(hipMemcpyAsync(out_host + (size_t)done * R.d, dout, (size_t)cnt * R.d * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(hipStreamSynchronize(h->stream));
-    }
+    const int64_t* src_ids = nullptr;
+    CHECK(resolve_rows(h, n, ids, &slots, &src_ids));
+    const size_t ids_bytes = ((size_t)n * 8 + 255) / 256 * 256;
+    const size_t neg_bytes = ((size_t)n_neg * R.d * 4 + 255) / 256 * 256;
+    CHECK(ensure_ws(h, 0, ids_bytes + 256 + neg_bytes + (size_t)n * n_neg * 4));
+    int64_t* dids = (int64_t*)h->ws[0];
+    int* bad = (int*)((char*)h->ws[0] + ids_bytes);
+    float* dneg = (float*)((char*)h->ws[0] + ids_bytes + 256);
+    float* dout = (float*)((char*)h->ws[0] + ids_bytes + 256 + neg_bytes);
+    HIPCHECK(hipMemcpyAsync(dids, src_ids, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipMemcpyAsync(dneg, neg_host, (size_t)n_neg * R.d * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipMemsetAsync(bad, 0, 4, h->stream));
+    RowView v = R.view();
+    if (h->kind == SSMI_KIND_IVFFLAT) v.nrows = h->ivf_slots_used;
+    HIPCHECK(launch_score_rows(v, R.dtype, dids, n, R.d, dneg, n_neg, dout, bad, h->stream));
+    HIPCHECK(hipMemcpyAsync(out_host, dout, (size_t)n * n_neg * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
     return 0;
     });
 }

@@ -137,7 +137,7 @@ struct ProbePlanRequest {
     bool done;
 };
 int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev, int k, float* Ddev, int64_t* Idev,
-                 int64_t id_offset, hipStream_t s, bool record, ProbePlanRequest* plan = nullptr);
+                 int64_t id_offset, hipStream_t s, bool record, ProbePlanRequest* plan = nullptr, unsigned min_ord = 0);
 
 // static_search.hip: resolves this device's copy of the static scratch array (once per device, device current)
 int static_scratch_setup(int device);
@@ -154,6 +154,6 @@ int ivf_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind
 int ivf_add_shard(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind, int64_t id0, int shard, int nshards);
 int ivf_add_random_unit(ssmi_index* h, int64_t n, uint64_t seed);
 int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev, int64_t* Idev, int64_t id_offset,
-               hipStream_t s);
+               hipStream_t s, unsigned min_ord = 0);
 int ivf_ids_to_slots(ssmi_index* h, int64_t n, const int64_t* ids, std::vector<int64_t>* slots);
 }  // namespace ssmi

@@ -193,8 +193,10 @@ __global__ void __launch_bounds__(256) ivf_scan_topk_kernel(IvfScanParams P) {
 
     WaveTopK<R> top;
     top.init();
-    skey_t thr = 0;
-    float thr_s = SSMI_NEG_MAX;
+    const skey_t thr_floor = floor_key(P.tail.min_ord);  // the search's score floor (0: none)
+    const float thr_floor_s = P.tail.min_ord ? ord_to_f32(P.tail.min_ord) : SSMI_NEG_MAX;
+    skey_t thr = thr_floor;
+    float thr_s = thr_floor_s;
 
     if (r < r_hi) {
         int lo = 0, hi = P.nprobe - 1;  // last j with pf[j] <= r
@@ -246,8 +248,8 @@ __global__ void __launch_bounds__(256) ivf_scan_topk_kernel(IvfScanParams P) {
                     const skey_t key = make_key(s, P.slot_ids[slot]);
                     if (key > thr) {
                         top.insert(key);
-                        thr = top.kth(P.k);
-                        thr_s = (thr == 0) ? SSMI_NEG_MAX : key_score(thr);
+                        thr = kmax(top.kth(P.k), thr_floor);
+                        thr_s = (thr == 0) ? SSMI_NEG_MAX : fmaxf(key_score(thr), thr_floor_s);
                     }
                 }
             }
@@ -260,7 +262,8 @@ __global__ void __launch_bounds__(256) ivf_scan_topk_kernel(IvfScanParams P) {
     if (P.tail.counter == nullptr) return;
     if (!tail_last_block(P.tail.counter + q, gridDim.x, reinterpret_cast<unsigned*>(lds_keys))) return;
     merge_partials<R, true>(P.partial + (size_t)q * gridDim.x * P.k, (int)gridDim.x, P.k, lds_keys, wave, 4,
-                      P.tail.D + (size_t)q * P.k, P.tail.I + (size_t)q * P.k, P.tail.id_offset);
+                      P.tail.D + (size_t)q * P.k, P.tail.I + (size_t)q * P.k, P.tail.id_offset,
+                      PlanOut{nullptr, nullptr, nullptr, nullptr}, P.tail.min_ord);
 }
 
 // K8, register-query form for rows of NCH KiB (d = 4096: NCH 8 for fp16, 16 for fp32; also 2048, 1024):
@@ -313,16 +316,18 @@ __global__ void __launch_bounds__((R <= 4 && ROWS == 1 && NCH * ElemTraits<T>::V
 
     WaveTopK<R> top;
     top.init();
-    skey_t thr = 0;
-    float thr_s = SSMI_NEG_MAX;
+    const skey_t thr_floor = floor_key(P.tail.min_ord);  // the search's score floor (0: none)
+    const float thr_floor_s = P.tail.min_ord ? ord_to_f32(P.tail.min_ord) : SSMI_NEG_MAX;
+    skey_t thr = thr_floor;
+    float thr_s = thr_floor_s;
 
     auto consider = [&](float s, uint32_t id) {
         if (s >= thr_s) {  // cheap float gate
             const skey_t key = make_key(s, id);
             if (key > thr) {
                 top.insert(key);
-                thr = top.kth(P.k);
-                thr_s = (thr == 0) ? SSMI_NEG_MAX : key_score(thr);
+                thr = kmax(top.kth(P.k), thr_floor);
+                thr_s = (thr == 0) ? SSMI_NEG_MAX : fmaxf(key_score(thr), thr_floor_s);
             }
         }
     };
@@ -433,7 +438,8 @@ __global__ void __launch_bounds__((R <= 4 && ROWS == 1 && NCH * ElemTraits<T>::V
     if (P.tail.counter == nullptr) return;
     if (!tail_last_block(P.tail.counter + q, gridDim.x, reinterpret_cast<unsigned*>(lds_keys))) return;
     merge_partials<R, true>(P.partial + (size_t)q * gridDim.x * P.k, (int)gridDim.x, P.k, lds_keys, wave, nwaves,
-                      P.tail.D + (size_t)q * P.k, P.tail.I + (size_t)q * P.k, P.tail.id_offset);
+                      P.tail.D + (size_t)q * P.k, P.tail.I + (size_t)q * P.k, P.tail.id_offset,
+                      PlanOut{nullptr, nullptr, nullptr, nullptr}, P.tail.min_ord);
 #ifdef SSMI_IVF_STAMP
     if (threadIdx.x == 0) P.dbg[(size_t)gridDim.x * nwaves * 4] = wall_clock64();
 #endif
@@ -846,7 +852,7 @@ static int qreg_threads(int dtype, int row_kib, int r, int rows) {
 }
 
 int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev, int64_t* Idev, int64_t id_offset,
-               hipStream_t s) {
+               hipStream_t s, unsigned min_ord) {
     IvfState* S = st(h);
     const RowStore& R = h->rows;
     CHECK(sync_csr(h));
@@ -943,7 +949,7 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
                 if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[1], s));
             }
             HIPCHECK(launch_merge_keys((const skey_t*)h->ws[2], nb, nprobe, k, Ddev + (size_t)done * k,
-                                       Idev + (size_t)done * k, id_offset, s));
+                                       Idev + (size_t)done * k, id_offset, s, min_ord));
             if (h->timing_on && done == 0) { HIPCHECK(hipEventRecord(ev[2], s)); h->merge_event = true; }
             continue;
         }
@@ -964,7 +970,7 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
         P.partial = (skey_t*)h->ws[2];
         const bool tail = h->tail_counters && nb <= ssmi_index::kTailCounters;
         P.tail = TailMerge{tail ? h->tail_counters : nullptr, Ddev + (size_t)done * k, Idev + (size_t)done * k, id_offset,
-                           nullptr, nullptr, nullptr, nullptr};
+                           nullptr, nullptr, nullptr, nullptr, min_ord};
         if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[0], s));
 #define IVF_LAUNCH(TT, RR)                                                                                       \
     case RR: {                                                                                                   \
@@ -1010,7 +1016,7 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
         if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[1], s));
         if (!tail)
             HIPCHECK(launch_merge_keys((const skey_t*)h->ws[2], nb, gx, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
-                                       id_offset, s));
+                                       id_offset, s, min_ord));
 #ifdef SSMI_IVF_STAMP
         if (qreg && getenv("SSMI_IVF_STAMP_PRINT")) {
             HIPCHECK(hipStreamSynchronize(s));

@@ -15,7 +15,7 @@ struct ScanPlan {
     int grid_x;    // row slices == partial lists per query
     int grid_y;    // query tiles
     size_t lds;    // dynamic LDS bytes
-    TailMerge tail = {nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};  // counter set: the scan writes (D, I) itself, no K3 launch
+    TailMerge tail = {nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};  // counter set: the scan writes (D, I) itself, no K3 launch
 };
 
 // K1 planning + launch
@@ -34,14 +34,14 @@ struct MfmaPlan {
 bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_cu, MfmaPlan* p);
 // Q: (nq, ld) fp32 on device; qh/cand: workspaces of p.qh_bytes / p.cand_bytes; partial: [nq][p.nslices][k]
 hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, const MfmaPlan& p, void* qh, void* cand,
-                            skey_t* partial, hipStream_t s);
+                            skey_t* partial, hipStream_t s, unsigned min_ord = 0);
 
 // (nq, ld) fp32 queries -> (rows_out >= nq, ld) fp16, zero rows beyond nq
 hipError_t launch_cvt_queries_f16(const float* q, int nq, int rows_out, int ld, void* out, hipStream_t s);
 
 // K3: merge P sorted k-lists of keys per query -> (D, I)
 hipError_t launch_merge_keys(const skey_t* partial, int nq, int P, int k, float* D, int64_t* I,
-                             int64_t id_offset, hipStream_t s);
+                             int64_t id_offset, hipStream_t s, unsigned min_ord = 0);
 // K3': merge `nlists` (D,I) result sets, each (nq,k) row-major, list l at Dl + l*d_stride / Il + l*i_stride
 hipError_t launch_merge_lists(const float* Dl, long long d_stride, const int64_t* Il, long long i_stride, int nlists,
                               int nq, int k, float* D, int64_t* I, hipStream_t s);
@@ -52,6 +52,9 @@ hipError_t launch_cvt_store(const void* src, int src_dtype, long long n, int d, 
 // K9: gather rows by id -> fp32 (n,d); ids out of range produce NaN-free zeros and set *bad
 hipError_t launch_gather_rows(const RowView& X, int dtype, const int64_t* ids, long long n, int d, float* out,
                               int* bad, hipStream_t s);
+// candidates x negatives inner products from the row store: out (n, n_neg) fp32
+hipError_t launch_score_rows(const RowView& X, int dtype, const int64_t* ids, long long n, int d, const float* neg,
+                             int n_neg, float* out, int* bad, hipStream_t s);
 // K10: append unit-norm gaussian rows [row0,row0+n)
 hipError_t launch_fill_random_unit(const RowView& X, int dtype, void* const* segs_rw, long long row0, long long n,
                                    int d, uint64_t seed, hipStream_t s);

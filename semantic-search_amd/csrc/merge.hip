@@ -15,12 +15,12 @@ namespace ssmi {
 
 template <int R>
 __global__ void merge_keys_kernel(const skey_t* __restrict__ partial, int P, int k, float* __restrict__ D,
-                                  int64_t* __restrict__ I, int64_t id_offset) {
+                                  int64_t* __restrict__ I, int64_t id_offset, unsigned min_ord) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int q = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     merge_partials<R, false>(partial + (size_t)q * P * k, P, k, reinterpret_cast<skey_t*>(smem), wave, (int)(blockDim.x >> 6),
-                      D + (size_t)q * k, I + (size_t)q * k, id_offset);
+                      D + (size_t)q * k, I + (size_t)q * k, id_offset, PlanOut{nullptr, nullptr, nullptr, nullptr}, min_ord);
 }
 
 // lists given as (D, I) pairs laid out [nlists][nq][k]
@@ -77,14 +77,14 @@ static int merge_waves(int P, int kp) {
 }
 
 hipError_t launch_merge_keys(const skey_t* partial, int nq, int P, int k, float* D, int64_t* I, int64_t id_offset,
-                             hipStream_t s) {
+                             hipStream_t s, unsigned min_ord) {
     if (nq <= 0) return hipSuccess;
     const int r = pow2_ceil((k + 63) / 64);
     const int w = merge_waves(P, 64 * r);
     const size_t lds = (size_t)w * 64 * r * sizeof(skey_t);
     return dispatch_r(r, [&](auto rc) {
         constexpr int R = decltype(rc)::value;
-        hipLaunchKernelGGL((merge_keys_kernel<R>), dim3(nq), dim3(64 * w), lds, s, partial, P, k, D, I, id_offset);
+        hipLaunchKernelGGL((merge_keys_kernel<R>), dim3(nq), dim3(64 * w), lds, s, partial, P, k, D, I, id_offset, min_ord);
         return hipGetLastError();
     });
 }

@@ -68,7 +68,7 @@ bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_c
 }
 
 hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, const MfmaPlan& p, void* qh, void* cand,
-                            skey_t* partial, hipStream_t s) {
+                            skey_t* partial, hipStream_t s, unsigned min_ord) {
     unsigned* gthr = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(qh) + (size_t)p.nqt * TN * X.ld * 2);
     const char* env_t = getenv("SSMI_MFMA_SHARE_THR");
     const bool share_thr = !(env_t && env_t[0] == '0');
@@ -79,6 +79,7 @@ hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, con
     P.X = X; P.Qh = (const _Float16*)qh; P.nq = nq; P.k = k; P.nqt = p.nqt; P.nslices = p.nslices;
     P.rows_per_slice = p.rows_per_slice; P.partial = partial; P.cand = (skey_t*)cand;
     P.gthr = (share_thr && p.nslices > 1) ? gthr : nullptr;
+    P.thr_floor = min_ord ? ord_to_f32(min_ord) : SSMI_NEG_MAX;
     int r = 1;
     while (64 * r < k) r <<= 1;
     if (p.narrow) {

@@ -19,6 +19,7 @@ struct MfmaParams {
     long long rows_per_slice;  // multiple of 256
     skey_t* partial;           // [nq][nslices][k]
     skey_t* cand;              // [gridDim.x][256][CAND_CAP]
+    float thr_floor;           // score floor of the search (SSMI_NEG_MAX = none): thresholds start and stay at or above it
     unsigned* gthr;            // [nqt*256] per query: highest k-th score any slice has reached (f32_to_ord bits,
                                // 0 = none), zeroed by the query conversion; 256-query kernel only
 #ifdef SSMI_STAMP
@@ -81,7 +82,7 @@ static constexpr int EPI_LDS_BYTES = 3 * 256 * 4 + 16;
 // `kept`: the query's k-list in global memory (k keys), valid once kept_l[ql] is set.
 template <int R>
 __device__ __forceinline__ void compact_list(int ql, skey_t* kept, int k, skey_t* cand_q, float* thr_l, unsigned* cnt_l,
-                                             unsigned* kept_l) {
+                                             unsigned* kept_l, float thr_floor = SSMI_NEG_MAX) {
     const int lane = lane_id();
     const int n = (int)min(cnt_l[ql], (unsigned)CAND_CAP);
     if (n == 0 && kept_l[ql]) return;  // nothing new: list and threshold stand
@@ -110,14 +111,14 @@ __device__ __forceinline__ void compact_list(int ql, skey_t* kept, int k, skey_t
     if (lane == 0) {
         kept_l[ql] = 1;
         cnt_l[ql] = 0;
-        thr_l[ql] = (thrk == 0) ? SSMI_NEG_MAX : key_score(thrk);
+        thr_l[ql] = (thrk == 0) ? thr_floor : fmaxf(key_score(thrk), thr_floor);
     }
 }
 // Flat kernels: query q of slice `slice` keeps its list at partial[q][slice][k]
 template <int R>
 __device__ __forceinline__ void compact_query(int ql, int q, const MfmaParams& P, int slice, skey_t* cand_q,
                                               float* thr_l, unsigned* cnt_l, unsigned* kept_l) {
-    compact_list<R>(ql, P.partial + ((size_t)q * P.nslices + slice) * P.k, P.k, cand_q, thr_l, cnt_l, kept_l);
+    compact_list<R>(ql, P.partial + ((size_t)q * P.nslices + slice) * P.k, P.k, cand_q, thr_l, cnt_l, kept_l, P.thr_floor);
 }
 
 // LDS atomic add / store issued as opaque instructions: after an LDS-DMA (global_load_lds) the
@@ -160,7 +161,7 @@ __device__ __forceinline__ FoldOperands<R> fold_load(int ql, const skey_t* kept,
 }
 template <int R>
 __device__ __forceinline__ void fold_one(int ql, const FoldOperands<R>& o, skey_t* kept, int k, const skey_t* cand_q,
-                                         float* thr_l, unsigned* cnt_l, unsigned* kept_l) {
+                                         float* thr_l, unsigned* cnt_l, unsigned* kept_l, float thr_floor) {
     const int lane = lane_id();
     if (o.n == 0 && o.has) return;  // nothing new: list and threshold stand
     WaveTopK<R> t;
@@ -188,7 +189,7 @@ __device__ __forceinline__ void fold_one(int ql, const FoldOperands<R>& o, skey_
     if (lane == 0) {
         lds_store(&kept_l[ql], 1u);
         lds_store(&cnt_l[ql], 0u);
-        lds_store(reinterpret_cast<unsigned*>(&thr_l[ql]), __float_as_uint((thrk == 0) ? SSMI_NEG_MAX : key_score(thrk)));
+        lds_store(reinterpret_cast<unsigned*>(&thr_l[ql]), __float_as_uint((thrk == 0) ? thr_floor : fmaxf(key_score(thrk), thr_floor)));
     }
 }
 template <int R>
@@ -204,7 +205,7 @@ __device__ __forceinline__ void fold_queries(int wave, int q0, const MfmaParams&
         const int qn = ql + 8;
         FoldOperands<R> nxt = cur;
         if (qn < nql) nxt = fold_load<R>(qn, list_of(qn), P.k, cand + (size_t)qn * CAND_CAP, cnt_l, kept_l);
-        fold_one<R>(ql, cur, list_of(ql), P.k, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
+        fold_one<R>(ql, cur, list_of(ql), P.k, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l, P.thr_floor);
         cur = nxt;
     }
 }

@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
 #ifdef SSMI_STAMP_NOPASS
         thr_l[tid] = __builtin_inff();
 #else
-        thr_l[tid] = (q0 + tid < P.nq) ? SSMI_NEG_MAX : __builtin_inff();
+        thr_l[tid] = (q0 + tid < P.nq) ? P.thr_floor : __builtin_inff();
 #endif
         cnt_l[tid] = 0;
         kept_l[tid] = 0;

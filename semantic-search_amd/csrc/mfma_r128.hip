@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
     skey_t* cand = P.cand + (size_t)blockIdx.x * N128_TN * CAND_CAP;
 
     if (tid < N128_TN) {
-        thr_l[tid] = (tid < P.nq) ? SSMI_NEG_MAX : __builtin_inff();
+        thr_l[tid] = (tid < P.nq) ? P.thr_floor : __builtin_inff();
         cnt_l[tid] = 0;
         kept_l[tid] = 0;
     }

@@ -121,8 +121,9 @@ __global__ void __launch_bounds__(QREG ? (R <= 4 ? 768 : 512) : 1024) flat_scan_
 
     WaveTopK<R> top[BT];
     skey_t thr[BT];
+    const skey_t thr_floor = floor_key(tail.min_ord);  // scores under the search's floor never enter a list
 #pragma unroll
-    for (int b = 0; b < BT; ++b) { top[b].init(); thr[b] = 0; }
+    for (int b = 0; b < BT; ++b) { top[b].init(); thr[b] = thr_floor; }
 
     for (long long row = r0 + wave; row < r1; row += nwaves) {
         const unsigned char* base = reinterpret_cast<const unsigned char*>(X.segs[row >> X.seg_shift]) +
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(QREG ? (R <= 4 ? 768 : 512) : 1024) flat_scan_
             const skey_t key = make_key(s, (uint32_t)row);
             if (key > thr[b]) {
                 top[b].insert(key);
-                thr[b] = top[b].kth(k);
+                thr[b] = kmax(top[b].kth(k), thr_floor);
             }
         }
     }
@@ -213,7 +214,7 @@ __global__ void __launch_bounds__(QREG ? (R <= 4 ? 768 : 512) : 1024) flat_scan_
         merge_partials<R, true>(partial + (size_t)q * gridDim.x * k, (int)gridDim.x, k, lds_keys, wave, nwaves,
                           tail.D + (size_t)q * k, tail.I + (size_t)q * k, tail.id_offset,
                           PlanOut{tail.plan_sizes, tail.plan_sizes ? tail.plan_prefix + (size_t)q * (k + 1) : nullptr,
-                                  tail.plan_page_off, tail.plan_sizes ? tail.plan_po + (size_t)q * k : nullptr});
+                                  tail.plan_page_off, tail.plan_sizes ? tail.plan_po + (size_t)q * k : nullptr}, tail.min_ord);
         __syncthreads();
     }
 }

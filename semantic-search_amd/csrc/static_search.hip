@@ -101,7 +101,7 @@ int ssmi_index_search_static(ssmi_index* h, int64_t nq, const float* q_dev, int 
     // the array keeps the previous call's contents: tickets must start at zero (a finished launch re-arms its own,
     // but this entry point does not rely on the previous user of the array having finished cleanly)
     HIPCHECK(hipMemsetAsync(counters, 0, (size_t)p.grid_y * sizeof(unsigned), s));
-    p.tail = TailMerge{counters, D_dev, I_dev, id_offset, nullptr, nullptr, nullptr, nullptr};
+    p.tail = TailMerge{counters, D_dev, I_dev, id_offset, nullptr, nullptr, nullptr, nullptr, 0};
     if (R.dtype == SSMI_F32) HIPCHECK(launch_flat_scan_f32(R.view(), q_dev, (int)nq, k, partial, p, s));
     else HIPCHECK(launch_flat_scan_f16(R.view(), q_dev, (int)nq, k, partial, p, s));
     return 0;

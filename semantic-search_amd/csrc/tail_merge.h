@@ -29,7 +29,12 @@ struct TailMerge {
     long long* plan_prefix;
     const int* plan_page_off;  // CSR offsets of the lists' page tables ...
     int* plan_po;              // ... gathered for the probed lists, (nq, k) int32
+    // score floor of the search (ssmi_index_search_min): f32_to_ord(min_score), 0 = none.  Results below it are
+    // never reported; the scans also start their thresholds there instead of at "anything goes"
+    unsigned min_ord;
 };
+// the key just below every key whose score is >= the floor (0: no floor)
+__host__ __device__ inline skey_t floor_key(unsigned min_ord) { return min_ord ? (((skey_t)min_ord << 32) - 1) : 0; }
 
 // K7 folded into a merge: ids of the sorted list -> exclusive prefix sum of list sizes (one wave, k <= 64)
 struct PlanOut {
@@ -57,14 +62,16 @@ __device__ __forceinline__ void write_plan(const WaveTopK<1>& t, int k, const Pl
 }
 
 template <int R>
-__device__ __forceinline__ void write_result(const WaveTopK<R>& t, int k, float* D, int64_t* I, int64_t id_offset) {
+__device__ __forceinline__ void write_result(const WaveTopK<R>& t, int k, float* D, int64_t* I, int64_t id_offset,
+                                             unsigned min_ord = 0) {
     const int lane = lane_id();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int e = r * 64 + lane;
         if (e < k) {
             const skey_t key = t.v[r];
-            if (key == 0) { D[e] = SSMI_NEG_MAX; I[e] = -1; }
+            // empty slot, or a score under the search's floor (the list is sorted: the cut is a suffix)
+            if (key == 0 || (unsigned)(key >> 32) < min_ord) { D[e] = SSMI_NEG_MAX; I[e] = -1; }
             else { D[e] = key_score(key); I[e] = (int64_t)key_id(key) + id_offset; }
         }
     }
@@ -92,7 +99,7 @@ static constexpr int kMergeSurvivorCap = 256;
 template <int R, bool COHERENT>
 __device__ __forceinline__ void merge_partials(const skey_t* lists, int P, int k, skey_t* lds, int wave, int nwaves,
                                                float* D, int64_t* I, int64_t id_offset,
-                                               PlanOut plan = PlanOut{nullptr, nullptr, nullptr, nullptr}) {
+                                               PlanOut plan = PlanOut{nullptr, nullptr, nullptr, nullptr}, unsigned min_ord = 0) {
     const int lane = lane_id();
     const int total = P * k;
     if (R == 1 && nwaves >= 5 && total > kMergeSurvivorCap) {
@@ -145,7 +152,7 @@ __device__ __forceinline__ void merge_partials(const skey_t* lists, int P, int k
                     WaveTopK<1> t;
                     t.v[0] = (unsigned)lane < n ? surv[lane] : 0;
                     t.sort_desc();
-                    write_result<1>(t, k, D, I, id_offset);
+                    write_result<1>(t, k, D, I, id_offset, min_ord);
                     if (plan.sizes) write_plan(t, k, plan);
                 } else {
                     WaveTopK<4> t;
@@ -154,7 +161,7 @@ __device__ __forceinline__ void merge_partials(const skey_t* lists, int P, int k
                     t.sort_desc();
                     WaveTopK<1> o;
                     o.v[0] = t.v[0];
-                    write_result<1>(o, k, D, I, id_offset);
+                    write_result<1>(o, k, D, I, id_offset, min_ord);
                     if (plan.sizes) write_plan(o, k, plan);
                 }
             }
@@ -194,7 +201,7 @@ __device__ __forceinline__ void merge_partials(const skey_t* lists, int P, int k
     }
     block_merge<R>(t, lds, wave, nwaves);
     if (wave == 0) {
-        write_result<R>(t, k, D, I, id_offset);
+        write_result<R>(t, k, D, I, id_offset, min_ord);
         if constexpr (R == 1) {
             if (plan.sizes) write_plan(t, k, plan);
         }

@@ -69,6 +69,47 @@ hipError_t launch_gather_rows(const RowView& X, int dtype, const int64_t* ids, l
     return hipGetLastError();
 }
 
+// candidates x negatives inner products straight from the row store (the exclusion filter of
+// core/index_manager.py:604-621: v = index.reconstruct(id); np.dot(v, neg)): one block per candidate id,
+// fp32 products and sums whatever the storage type; out is (n, n_neg) row-major.
+template <typename T>
+__global__ void __launch_bounds__(256) score_rows_kernel(RowView X, const int64_t* __restrict__ ids, long long n, int d,
+                                                         const float* __restrict__ neg, int n_neg, float* __restrict__ out,
+                                                         int* __restrict__ bad) {
+    __shared__ float part[4];
+    const long long i = blockIdx.x;
+    if (i >= n) return;
+    const int64_t id = ids[i];
+    if (id < 0 || id >= X.nrows) {
+        for (int j = threadIdx.x; j < n_neg; j += blockDim.x) out[(size_t)i * n_neg + j] = 0.f;
+        if (threadIdx.x == 0) atomicExch(bad, 1);
+        return;
+    }
+    const long long mask = (1ll << X.seg_shift) - 1;
+    const T* src = reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(X.segs[id >> X.seg_shift]) +
+                                              (size_t)(id & mask) * (size_t)X.ld * sizeof(T));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = 0; j < n_neg; ++j) {
+        const float* q = neg + (size_t)j * d;
+        float acc = 0.f;
+        for (int e = threadIdx.x; e < d; e += blockDim.x) acc = fmaf((float)src[e], q[e], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) part[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) out[(size_t)i * n_neg + j] = (part[0] + part[1]) + (part[2] + part[3]);
+        __syncthreads();
+    }
+}
+
+hipError_t launch_score_rows(const RowView& X, int dtype, const int64_t* ids, long long n, int d, const float* neg,
+                             int n_neg, float* out, int* bad, hipStream_t s) {
+    if (n <= 0 || n_neg <= 0) return hipSuccess;
+    const dim3 grid((unsigned)n), block(256);
+    if (dtype == 0) hipLaunchKernelGGL((score_rows_kernel<float>), grid, block, 0, s, X, ids, n, d, neg, n_neg, out, bad);
+    else hipLaunchKernelGGL((score_rows_kernel<__half>), grid, block, 0, s, X, ids, n, d, neg, n_neg, out, bad);
+    return hipGetLastError();
+}
+
 // ---- Philox4x32-10 ---------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t* out) {

@@ -33,6 +33,7 @@ import torch
 
 from . import _lib
 
+_NO_FLOOR = -3.4028234663852886e38  # -FLT_MAX: ssmi_index_search_min's "no score floor"
 METRIC_INNER_PRODUCT = 0
 METRIC_L2 = 1
 
@@ -155,8 +156,11 @@ class _IndexBase:
         _lib.check(self._lib.ssmi_index_add_random_unit(self._handle(), int(n), int(seed)))
 
     # -- search -----------------------------------------------------------
-    def search(self, x, k: int, id_offset: int = 0, out=None):
+    def search(self, x, k: int, id_offset: int = 0, out=None, min_score: Optional[float] = None):
         """(D, I) = top-k inner products of each query row.
+
+        min_score (additive; the search nodes' filter, nodes/search_nodes.py:152-159): only results with
+        score >= min_score are reported, the rest of a row is -1 / -FLT_MAX padding; applied inside the kernels.
 
         numpy in -> numpy out (D float32 (n,k) sorted descending, I int64, -1 padded).
         A torch tensor on the index's device -> torch tensors on that device,
@@ -165,6 +169,7 @@ class _IndexBase:
         k = int(k)
         if k < 1:
             raise RuntimeError("search: k must be >= 1")
+        floor = _NO_FLOOR if min_score is None else float(min_score)
         if isinstance(x, torch.Tensor) and x.is_cuda:
             if x.dim() == 1:
                 x = x.reshape(1, -1)
@@ -180,8 +185,8 @@ class _IndexBase:
                 D = torch.empty((nq, k), dtype=torch.float32, device=x.device)
                 I = torch.empty((nq, k), dtype=torch.int64, device=x.device)
             stream = torch.cuda.current_stream(x.device).cuda_stream
-            _lib.check(self._lib.ssmi_index_search(self._handle(), nq, x.data_ptr(), _lib.DEVICE, k, D.data_ptr(),
-                                                   I.data_ptr(), _lib.DEVICE, int(id_offset), stream))
+            _lib.check(self._lib.ssmi_index_search_min(self._handle(), nq, x.data_ptr(), _lib.DEVICE, k, floor, D.data_ptr(),
+                                                       I.data_ptr(), _lib.DEVICE, int(id_offset), stream))
             return D, I
         if isinstance(x, torch.Tensor):
             x = x.numpy()
@@ -189,8 +194,8 @@ class _IndexBase:
         nq = x.shape[0]
         D = np.empty((nq, k), dtype=np.float32)
         I = np.empty((nq, k), dtype=np.int64)
-        _lib.check(self._lib.ssmi_index_search(self._handle(), nq, x.ctypes.data, _lib.HOST, k, D.ctypes.data,
-                                               I.ctypes.data, _lib.HOST, int(id_offset), None))
+        _lib.check(self._lib.ssmi_index_search_min(self._handle(), nq, x.ctypes.data, _lib.HOST, k, floor, D.ctypes.data,
+                                                   I.ctypes.data, _lib.HOST, int(id_offset), None))
         return D, I
 
     def search_static(self, x: torch.Tensor, k: int, out, id_offset: int = 0) -> None:
@@ -215,6 +220,24 @@ class _IndexBase:
         ids = np.ascontiguousarray(np.asarray(ids, dtype=np.int64).reshape(-1))
         out = np.empty((ids.shape[0], self.d), dtype=np.float32)
         _lib.check(self._lib.ssmi_index_reconstruct_n(self._handle(), ids.shape[0], ids.ctypes.data, out.ctypes.data))
+        return out
+
+    def reconstruct_batch_device(self, ids) -> torch.Tensor:
+        """Stored vectors `ids` as a float32 (n,d) tensor on the index's GPU (no host copy of the vectors)."""
+        ids = np.ascontiguousarray(np.asarray(ids, dtype=np.int64).reshape(-1))
+        out = torch.empty((ids.shape[0], self.d), dtype=torch.float32, device=torch.device("cuda", self.device))
+        torch.cuda.current_stream(out.device).synchronize()
+        _lib.check(self._lib.ssmi_index_reconstruct_n_dev(self._handle(), ids.shape[0], ids.ctypes.data, out.data_ptr()))
+        return out
+
+    def score_ids(self, ids, vectors) -> np.ndarray:
+        """Inner products of the stored vectors `ids` with each row of `vectors`: (len(ids), len(vectors)) float32,
+        computed on the device (the exclusion filter of core/index_manager.py:604-621 in one call)."""
+        ids = np.ascontiguousarray(np.asarray(ids, dtype=np.int64).reshape(-1))
+        v = _as_f32_matrix(vectors, self.d, "score_ids")
+        out = np.empty((ids.shape[0], v.shape[0]), dtype=np.float32)
+        _lib.check(self._lib.ssmi_index_score_ids(self._handle(), ids.shape[0], ids.ctypes.data, v.shape[0], v.ctypes.data,
+                                                  out.ctypes.data))
         return out
 
     def reconstruct(self, i: int) -> np.ndarray:

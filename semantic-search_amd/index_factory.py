@@ -176,18 +176,35 @@ class IndexFactory:
             index.hnsw.efSearch = config.hnsw_ef_search
 
     # -- shared tail of rebuild/compact -------------------------------------
+    _CHUNK_ROWS = 65536  # rows moved per step (1 GiB of fp32 at d = 4096), all of it in HBM
+
     @staticmethod
-    def _build_from(vectors: np.ndarray, config: IndexConfig):
+    def _build_from_index(old_index, ids: np.ndarray, config: IndexConfig):
+        """New index holding the vectors `ids` of old_index in that order, DEVICE-RESIDENT: rows are gathered on
+        the GPU (ssmi_index_reconstruct_n_dev) and handed to train()/add() as device tensors chunk by chunk, so no
+        (N, d) host array exists at any point (the reference's loops: core/index_factory.py:273-274,371-372 fill
+        one).  Raises RuntimeError when the old index cannot reconstruct (IVF without a
+        direct map), like the reference's reconstruct() does."""
         index = IndexFactory.create_index(config)
+        n = len(ids)
         if IndexFactory.needs_training(index):
-            sample = vectors
-            if len(vectors) > _TRAIN_SAMPLE_CAP:
-                sample = vectors[np.random.choice(len(vectors), _TRAIN_SAMPLE_CAP, replace=False)]
-            if not IndexFactory.train_index(index, sample):
+            sample = ids
+            if n > _TRAIN_SAMPLE_CAP:
+                sample = np.sort(ids[np.random.choice(n, _TRAIN_SAMPLE_CAP, replace=False)])
+            ok = False
+            try:
+                index.train(old_index.reconstruct_batch_device(sample))
+                ok = bool(index.is_trained)
+            except RuntimeError as e:
+                if "reconstruct" in str(e) or "direct map" in str(e):
+                    raise
+                print(f"[SemanticSearch] Index training failed: {e}")
+            if not ok:
                 print("[SemanticSearch] Warning: Training failed, falling back to Flat index")
                 config.index_type = IndexType.FLAT
                 index = IndexFactory.create_index(config)
-        index.add(vectors)
+        for s0 in range(0, n, IndexFactory._CHUNK_ROWS):
+            index.add(old_index.reconstruct_batch_device(ids[s0:s0 + IndexFactory._CHUNK_ROWS]))
         return index
 
     @staticmethod
@@ -199,15 +216,15 @@ class IndexFactory:
             return IndexFactory.create_index(new_config), True
         report(0, n, "Extracting vectors from old index...")
         try:
-            vectors = old_index.reconstruct_batch(np.arange(n, dtype=np.int64))
+            old_index.reconstruct_batch_device(np.zeros((1,), dtype=np.int64))   # can this index give its vectors back?
         except RuntimeError:
             print("[SemanticSearch] Warning: Cannot reconstruct vectors from this index type")
             return old_index, False
         report(n // 2, n, "Creating new index...")
         if new_config.index_type in (IndexType.IVF_FLAT, IndexType.IVF_PQ):
             report(n // 2, n, "Training new index...")
-        new_index = IndexFactory._build_from(vectors, new_config)
         report(n * 3 // 4, n, "Adding vectors to new index...")
+        new_index = IndexFactory._build_from_index(old_index, np.arange(n, dtype=np.int64), new_config)
         report(n, n, "Rebuild complete")
         return new_index, True
 
@@ -225,11 +242,10 @@ class IndexFactory:
         keep = sorted(valid_vector_ids)
         id_mapping = {old: new for new, old in enumerate(keep)}
         try:
-            vectors = old_index.reconstruct_batch(np.asarray(keep, dtype=np.int64))
+            report(n_valid, n_valid, "Creating compacted index...")
+            new_index = IndexFactory._build_from_index(old_index, np.asarray(keep, dtype=np.int64), new_config)
         except RuntimeError as e:
             print(f"[SemanticSearch] Warning: Cannot reconstruct vectors: {e}")
             return old_index, {}, False
-        report(n_valid, n_valid, "Creating compacted index...")
-        new_index = IndexFactory._build_from(vectors, new_config)
         report(n_valid, n_valid, f"Compaction complete: {n_total} -> {n_valid} vectors")
         return new_index, id_mapping, True

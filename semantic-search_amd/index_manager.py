@@ -305,13 +305,11 @@ class SemanticIndex:
         return SearchResults(out, query_type, "")
 
     @staticmethod
-    def _apply_min_score(scores: np.ndarray, indices: np.ndarray, min_score: float):
+    def _floor(min_score: float) -> Optional[float]:
         """The search nodes' score filter (nodes/search_nodes.py:152-159: keep r.score >= min_score when
-        min_score > 0), applied to the engine's sorted result row before any metadata is looked up."""
-        if min_score is None or min_score <= 0.0:
-            return scores, indices
-        keep = int(np.searchsorted(-scores, -np.float32(min_score), side="right"))  # scores are sorted descending
-        return scores[:keep], indices[:keep]
+        min_score > 0) as the engine's score floor: applied inside the kernels (ssmi_index_search_min), so rows
+        come back already cut and padded with -1, which _results_from drops like any short result."""
+        return float(min_score) if (min_score is not None and min_score > 0.0) else None
 
     def search(self, query_vector: np.ndarray, top_k: int = DEFAULT_TOP_K, min_score: float = 0.0) -> SearchResults:
         """:348-398 (min_score is additive: SURVEY.md 8f rank 3)"""
@@ -320,32 +318,32 @@ class SemanticIndex:
             q = q.reshape(1, -1)
         q = np.ascontiguousarray(q.astype(np.float32))
         with self._lock:
-            scores, indices = self._faiss_index.search(q, top_k)
-        return self._results_from(*self._apply_min_score(scores[0], indices[0], min_score), "vector")
+            scores, indices = self._faiss_index.search(q, top_k, min_score=self._floor(min_score))
+        return self._results_from(scores[0], indices[0], "vector")
 
     def search_batch(self, query_vectors: np.ndarray, top_k: int = DEFAULT_TOP_K, min_score: float = 0.0) -> List[SearchResults]:
         """Additive: every row of a (B, d) query matrix, one engine call (MFMA path for large B)."""
         q = np.ascontiguousarray(np.atleast_2d(np.asarray(query_vectors)).astype(np.float32))
         with self._lock:
-            scores, indices = self._faiss_index.search(q, top_k)
-        return [self._results_from(*self._apply_min_score(s, i, min_score), "vector") for s, i in zip(scores, indices)]
+            scores, indices = self._faiss_index.search(q, top_k, min_score=self._floor(min_score))
+        return [self._results_from(s, i, "vector") for s, i in zip(scores, indices)]
 
     def search_with_exclusion(self, query_vector: np.ndarray, negative_vectors: List[np.ndarray], top_k: int = DEFAULT_TOP_K,
                               exclusion_threshold: float = 0.3) -> SearchResults:
         """Vector-level form of search_by_text_with_exclusion (:553-633): over-fetch
         min(3*top_k, 500) candidates, drop those whose stored vector has inner product
-        >= threshold with any negative vector.  One bulk read-back replaces the
-        per-candidate reconstruct() calls (:606-612)."""
+        >= threshold with any negative vector.  One device launch (ssmi_index_score_ids)
+        replaces the per-candidate reconstruct() + np.dot calls (:606-621)."""
         candidates = self.search(query_vector, min(top_k * 3, MAX_TOP_K))
         if not candidates.results or not negative_vectors:
             return SearchResults(candidates.results[:top_k], "vector_with_exclusion", "")
         neg = np.stack([np.asarray(v, dtype=np.float32).reshape(-1) for v in negative_vectors])
         with self._lock:
-            try:
-                vecs = self._faiss_index.reconstruct_batch([r.vector_id for r in candidates.results])
+            try:   # candidates x negatives inner products in one device launch (no vectors travel to the host)
+                sims = self._faiss_index.score_ids([r.vector_id for r in candidates.results], neg)
             except RuntimeError:
                 return SearchResults([], "vector_with_exclusion", "")   # :610-612 skips what it cannot reconstruct
-        keep = ~((vecs @ neg.T) >= exclusion_threshold).any(axis=1)
+        keep = ~(sims >= exclusion_threshold).any(axis=1)
         kept = [r for r, k in zip(candidates.results, keep) if k][:top_k]
         return SearchResults(kept, "vector_with_exclusion", "")
 
@@ -466,11 +464,32 @@ def search_multi_index(indexes: List["SemanticIndex"], query_vector: np.ndarray,
     then the min_score filter (:891-898).  The node re-encodes the text once per index (:871-878); here the caller
     encodes once and passes the vector."""
     per_index_k = max(top_k, 50)
-    merged = SemanticIndex.merge_search_results([ix.search(query_vector, per_index_k) for ix in indexes if ix is not None],
-                                                top_k=top_k, normalize_scores=normalize_scores)
+    live = [ix for ix in indexes if ix is not None]
+    merged = SemanticIndex.merge_search_results(_search_all(live, query_vector, per_index_k), top_k=top_k,
+                                                normalize_scores=normalize_scores)
     if min_score > 0.0:
         merged = SearchResults([r for r in merged.results if r.score >= min_score], merged.query_type, merged.query_info)
     return merged
+
+
+def _search_all(indexes: List["SemanticIndex"], query_vector: np.ndarray, k: int) -> List[SearchResults]:
+    """One query against several indexes without a host round trip per index: the query goes to the device once,
+    every index's search is enqueued on the current stream with device outputs, and all results come back in one
+    synchronisation (the node searches its indexes one after the other, nodes/search_nodes.py:871-878).  Indexes
+    on different GPUs, or an engine without device tensors, take the serial path."""
+    import torch
+    devs = {getattr(ix._faiss_index, "device", None) for ix in indexes}
+    if len(indexes) < 2 or len(devs) != 1 or None in devs or not torch.cuda.is_available():
+        return [ix.search(query_vector, k) for ix in indexes]
+    q = torch.from_numpy(np.ascontiguousarray(np.asarray(query_vector, dtype=np.float32).reshape(1, -1))).to(
+        torch.device("cuda", devs.pop()))
+    outs = []
+    for ix in indexes:
+        with ix._lock:
+            outs.append(ix._faiss_index.search(q, k))
+    D = torch.stack([o[0][0] for o in outs]).cpu().numpy()     # one synchronising copy for all indexes
+    I = torch.stack([o[1][0] for o in outs]).cpu().numpy()
+    return [ix._results_from(D[j], I[j], "vector") for j, ix in enumerate(indexes)]
 
 
 def get_or_create_index(index_name: str, embedding_dim: int = 4096, index_type: str = "flat", **kwargs) -> SemanticIndex:

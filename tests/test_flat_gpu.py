@@ -252,6 +252,34 @@ def test_large_random_unit_matches_oracle_on_readback(ssa):
     _check(index, X, unit_rows(2, d, 4321), 10)
 
 
+@pytest.mark.parametrize("storage,nq", [("f32", 1), ("f32", 8), ("f16", 3), ("f16", 64), ("f16", 300), ("f32", 40)])
+def test_min_score_floor_inside_the_kernels(ssa, storage, nq):
+    """ssmi_index_search_min on every Flat path (K1 register / LDS query, K2r, K2, the fp16 shadow): a row must equal
+    the unfloored row cut where the score drops below min_score and padded with -1 / -FLT_MAX - exactly the search
+    nodes' `r.score >= min_score` filter (nodes/search_nodes.py:152-159) - and agree with the oracle cut the same way."""
+    n, d, k = 30000, 1024, 20
+    X = unit_rows(n, d, 61)
+    Xs = X if storage == "f32" else X.astype(np.float16).astype(np.float32)
+    Q = unit_rows(nq, d, 62)
+    index = ssa.IndexFlatIP(d, storage=storage)
+    index.add(X)
+    D0, I0 = index.search(Q, k)
+    path = index.last_timing()["last_path"]
+    for floor in (float(np.median(D0[:, k // 2])), float(D0.max()) + 1.0, -1.0, float(D0[0, 3])):
+        D, I = index.search(Q, k, min_score=floor)
+        assert index.last_timing()["last_path"] == path
+        keep = D0 >= np.float32(floor)
+        np.testing.assert_array_equal(I, np.where(keep, I0, -1))
+        np.testing.assert_array_equal(D, np.where(keep, D0, flat_ip.NEG_MAX))
+    if path == 0:   # exact paths: the oracle, cut the same way
+        Dr, Ir = flat_ip.search(Xs, Q, k)
+        floor = float(np.median(Dr[:, 5]))
+        D, I = index.search(Q, k, min_score=floor)
+        keep = Dr >= np.float32(floor) * (1 + 1e-6)          # entries at the floor within rounding may go either way
+        assert ((I >= 0) >= keep).all() and (np.where(keep, I, 0) == np.where(keep, Ir, 0)).all()
+    index.close()
+
+
 def test_one_handle_searched_from_two_streams_and_adds_in_between(ssa):
     """Device-buffer searches return after enqueueing while the handle's workspaces are shared: searches issued
     from two streams are ordered behind one another by the library, and an add waits for the searches in flight

@@ -292,6 +292,28 @@ def test_many_probes_and_both_merge_forms(ssa, monkeypatch, no_tail):
     index.close()
 
 
+@pytest.mark.parametrize("storage,nq,listmajor", [("f32", 1, "0"), ("f16", 5, "0"), ("f16", 64, "1"), ("f32", 40, "1")])
+def test_min_score_floor_on_the_ivf_scans(ssa, monkeypatch, storage, nq, listmajor):
+    """The score floor on the per-query IVF scans (thresholds start at the floor, merge tail cuts) and on the
+    list-major scans (cut in the merge): floored rows == unfloored rows cut at the floor."""
+    monkeypatch.setenv("SSMI_IVF_LISTMAJOR", listmajor)
+    n, d, nlist, k = 8000, 512, 16, 20
+    X, C = clustered_rows(n, d, nlist, 91), clustered_rows(nlist, d, nlist, 92)
+    index = make_ivf(ssa, d, nlist, storage)
+    index.set_centroids(C)
+    index.add(X)
+    index.nprobe = 5
+    Q = clustered_rows(nq, d, nlist, 93)
+    D0, I0 = index.search(Q, k)
+    assert (index.last_timing()["last_grid"] < 0) == (listmajor == "1")
+    for floor in (float(np.median(D0[:, k // 2])), 2.0, -1.0):
+        D, I = index.search(Q, k, min_score=floor)
+        keep = D0 >= np.float32(floor)
+        np.testing.assert_array_equal(I, np.where(keep, I0, -1))
+        np.testing.assert_array_equal(D, np.where(keep, D0, flat_ip.NEG_MAX))
+    index.close()
+
+
 def test_fp32_lists_shadow_follows_adds(ssa):
     """The fp16 shadow of an fp32 slot store is built by the first batched search and must then follow every add
     (rows appended into half-filled pages included): a batched search after more adds sees all rows."""

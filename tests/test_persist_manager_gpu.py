@@ -116,6 +116,45 @@ def test_factory_rebuild_and_compact_on_device(ssa):
     assert ok and fresh.ntotal == 0 and not fresh.is_trained
 
 
+def test_device_resident_rebuild_compact_and_exclusion_scores(ssa, monkeypatch):
+    """rows move from the old index to the new one on the GPU (chunked device gather ->
+    train/add with device tensors), and the exclusion filter's candidate x negative products are one device
+    launch; both against numpy on the host copies the test holds."""
+    F, C, T = ssa.IndexFactory, ssa.IndexConfig, ssa.IndexType
+    d = 256
+    X = unit_rows(5000, d, 71)
+    for storage in ("f32", "f16"):
+        Xs = X if storage == "f32" else X.astype(np.float16).astype(np.float32)
+        flat = ssa.IndexFlatIP(d, storage=storage)
+        flat.add(X)
+        ids = np.array([0, 4999, 17, 17, 2500], dtype=np.int64)
+        dev = flat.reconstruct_batch_device(ids)
+        assert dev.is_cuda and dev.dtype.is_floating_point and tuple(dev.shape) == (5, d)
+        np.testing.assert_array_equal(dev.cpu().numpy(), Xs[ids])
+        np.testing.assert_array_equal(dev.cpu().numpy(), flat.reconstruct_batch(ids))
+        neg = unit_rows(3, d, 72)
+        sims = flat.score_ids(ids, neg)
+        np.testing.assert_allclose(sims, Xs[ids] @ neg.T, rtol=1e-5, atol=1e-6)
+        with pytest.raises(RuntimeError):
+            flat.score_ids([5000], neg)
+        # rebuild in chunks of 700 rows (several chunks, a ragged last one), Flat -> IVF with training on device rows
+        monkeypatch.setattr(F, "_CHUNK_ROWS", 700)
+        ivf, ok = F.rebuild_index(flat, C(T.IVF_FLAT, d, nlist=16, nprobe=16, extra={"storage": storage}))
+        assert ok and ivf.ntotal == 5000 and ivf.is_trained and ivf.storage == storage
+        Q = unit_rows(4, d, 73)
+        D0, I0 = flat.search(Q, 10); D1, I1 = ivf.search(Q, 10)
+        np.testing.assert_array_equal(I1, I0)          # nprobe == nlist: exact, ids kept their positions
+        np.testing.assert_allclose(D1, D0, rtol=1e-6)
+        ivf.make_direct_map()
+        np.testing.assert_allclose(ivf.score_ids(ids, neg), Xs[ids] @ neg.T, rtol=1e-5, atol=1e-6)   # IVF: through the direct map
+        keep = list(range(0, 5000, 3))
+        small, mapping, ok = F.compact_index(ivf, keep, C(T.FLAT, d, extra={"storage": storage}))
+        assert ok and small.ntotal == len(keep) and mapping[3] == 1 and mapping[4998] == len(keep) - 1
+        np.testing.assert_array_equal(small.reconstruct_n(0, len(keep)), Xs[keep])
+        for ix in (flat, ivf, small):
+            ix.close()
+
+
 def test_semantic_index_lifecycle(ssa, tmp_path):
     from semantic_search_amd.index_manager import SemanticIndex
     d = 96
