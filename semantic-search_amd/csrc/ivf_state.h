@@ -22,6 +22,13 @@ struct IvfState {
     bool csr_dirty = true;
     bool has_direct_map = false;
     std::vector<int64_t> direct_map;  // id -> slot
+    // incremental persistence (persist.hip): the file this index was last written to / read from in full, and
+    // how much of every list that file plus its journal already hold
+    std::string persist_path;              // empty: no full write or read yet
+    long long persist_base_ntotal = -1;    // ntotal in the base file's header
+    unsigned long long persist_base_bytes = 0;  // size of the base file
+    long long persist_journal_rows = 0;    // vectors the journal holds
+    std::vector<long long> persist_size;   // per list: members already on disk (base + journal)
     int niter = 10;                   // [FAISS-lib] ClusteringParameters default for the IVF quantizer
     int max_points_per_centroid = 256;
     uint64_t seed = 1234;

@@ -85,6 +85,119 @@ int write_flat_payload(ssmi_index* h, const RowStore& R, long long nrows, FILE* 
     return 0;
 }
 
+// ---- IVF journal (our own side file "<path>.journal"; the base file stays a plain FAISS IwFl file) -------------
+//   "SSJ1" | d:i32 | nlist:u64 | base_ntotal:i64 | base_bytes:u64          header, ties the journal to ONE base file
+//   "chnk" | n:u64 | labels:i32[n] | ids:i64[n] | vectors:f32[n*d]         one record per incremental checkpoint
+// A record is valid only if it is complete; a torn tail (crash while appending) is ignored by the reader.
+const size_t kJournalHeader = 4 + 4 + 8 + 8 + 8;
+std::string journal_path(const char* path) { return std::string(path) + ".journal"; }
+
+unsigned long long file_bytes(const char* path) {
+    File F;
+    F.f = fopen(path, "rb");
+    if (!F.f || fseek(F.f, 0, SEEK_END) != 0) return 0;
+    const long n = ftell(F.f);
+    return n < 0 ? 0 : (unsigned long long)n;
+}
+
+void record_full_state(ssmi_index* h, const char* path) {
+    IvfState* S = st(h);
+    S->persist_path = path;
+    S->persist_base_ntotal = h->ivf_ntotal;
+    S->persist_base_bytes = file_bytes(path);
+    S->persist_journal_rows = 0;
+    S->persist_size = S->size;
+}
+
+// members each list gained since the last checkpoint -> one journal record
+int append_journal(ssmi_index* h, const char* path) {
+    IvfState* S = st(h);
+    const RowStore& R = h->rows;
+    const std::string jp = journal_path(path);
+    std::vector<int32_t> labels;
+    std::vector<int64_t> slots;
+    for (int l = 0; l < h->nlist; ++l)
+        for (long long pos = S->persist_size[l]; pos < S->size[l]; ++pos) {
+            labels.push_back(l);
+            slots.push_back((long long)S->pages[l][pos >> kPageShift] * kPageRows + (pos & (kPageRows - 1)));
+        }
+    const int64_t n = (int64_t)labels.size();
+    if (n == 0) return 0;
+    std::vector<uint32_t> sids((size_t)h->ivf_slots_used);
+    HIPCHECK(hipMemcpy(sids.data(), S->d_slot_ids, sids.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<int64_t> ids64((size_t)n);
+    for (int64_t i = 0; i < n; ++i) ids64[i] = (int64_t)sids[(size_t)slots[i]];
+    const bool fresh = file_bytes(jp.c_str()) < kJournalHeader;
+    File F;
+    F.f = fopen(jp.c_str(), fresh ? "wb" : "ab");
+    if (!F.f) return fail("write_index: cannot open %s", jp.c_str());
+    FILE* f = F.f;
+    if (fresh && !(wr(f, "SSJ1", 4) && wr1<int32_t>(f, R.d) && wr1<uint64_t>(f, (uint64_t)h->nlist) &&
+                   wr1<int64_t>(f, S->persist_base_ntotal) && wr1<uint64_t>(f, S->persist_base_bytes)))
+        return fail("write_index: journal write failed");
+    if (!(wr(f, "chnk", 4) && wr1<uint64_t>(f, (uint64_t)n) && wr(f, labels.data(), (size_t)n * 4) && wr(f, ids64.data(), (size_t)n * 8)))
+        return fail("write_index: journal write failed");
+    const int64_t chunk = std::max<int64_t>(1, ((size_t)64 << 20) / ((size_t)R.d * 4));
+    std::vector<float> buf((size_t)std::min(chunk, n) * R.d);
+    for (int64_t done = 0; done < n; done += chunk) {
+        const int64_t cnt = std::min(chunk, n - done);
+        CHECK(read_rows(h, R, h->ivf_slots_used, slots.data() + done, cnt, buf.data()));
+        if (!wr(f, buf.data(), (size_t)cnt * R.d * 4)) return fail("write_index: journal write failed");
+    }
+    if (fflush(f) != 0) return fail("write_index: flush failed for %s", jp.c_str());
+    S->persist_journal_rows += n;
+    S->persist_size = S->size;
+    return 0;
+}
+
+// replay "<path>.journal" into a freshly read base index; a journal of another base file is ignored
+int replay_journal(ssmi_index* h, const char* path, int64_t base_ntotal) {
+    IvfState* S = st(h);
+    const int d = h->rows.d;
+    const std::string jp = journal_path(path);
+    const unsigned long long jbytes = file_bytes(jp.c_str());
+    if (jbytes < kJournalHeader) return 0;
+    File F;
+    F.f = fopen(jp.c_str(), "rb");
+    if (!F.f) return 0;
+    FILE* f = F.f;
+    char cc[4];
+    int32_t jd; uint64_t jnlist, jbase_bytes; int64_t jbase_nt;
+    if (!(rd(f, cc, 4) && rd1(f, &jd) && rd1(f, &jnlist) && rd1(f, &jbase_nt) && rd1(f, &jbase_bytes))) return 0;
+    if (memcmp(cc, "SSJ1", 4) != 0 || jd != d || jnlist != (uint64_t)h->nlist || jbase_nt != base_ntotal ||
+        jbase_bytes != file_bytes(path))
+        return 0;  // belongs to an earlier base file: stale, the base alone is the index
+    unsigned long long pos = kJournalHeader;
+    const uint64_t rec = 4 + 8 + (uint64_t)d * 4;
+    const int64_t chunk = std::max<int64_t>(1, ((size_t)64 << 20) / ((size_t)d * 4));
+    std::vector<int32_t> labels; std::vector<int64_t> ids64; std::vector<uint32_t> ids32; std::vector<float> buf; std::vector<int> lab;
+    while (pos + 12 <= jbytes) {
+        uint64_t n;
+        if (fseek(f, (long)pos, SEEK_SET) != 0 || !rd(f, cc, 4) || memcmp(cc, "chnk", 4) != 0 || !rd1(f, &n)) break;
+        if (n == 0 || n > (jbytes - pos - 12) / rec) break;  // torn tail: the complete records before it stand
+        const unsigned long long lab0 = pos + 12, ids0 = lab0 + n * 4, vec0 = ids0 + n * 8;
+        for (uint64_t done = 0; done < n; done += (uint64_t)chunk) {
+            const int64_t cnt = (int64_t)std::min<uint64_t>((uint64_t)chunk, n - done);
+            labels.resize((size_t)cnt); ids64.resize((size_t)cnt); ids32.resize((size_t)cnt); buf.resize((size_t)cnt * d); lab.resize((size_t)cnt);
+            if (fseek(f, (long)(lab0 + done * 4), SEEK_SET) != 0 || !rd(f, labels.data(), (size_t)cnt * 4) ||
+                fseek(f, (long)(ids0 + done * 8), SEEK_SET) != 0 || !rd(f, ids64.data(), (size_t)cnt * 8) ||
+                fseek(f, (long)(vec0 + done * (uint64_t)d * 4), SEEK_SET) != 0 || !rd(f, buf.data(), (size_t)cnt * d * 4))
+                return fail("read_index: journal %s is unreadable", jp.c_str());
+            for (int64_t i = 0; i < cnt; ++i) {
+                if (labels[i] < 0 || labels[i] >= h->nlist || ids64[i] < 0 || ids64[i] >= 0xFFFFFFFFll)
+                    return fail("read_index: corrupt journal record in %s", jp.c_str());
+                lab[i] = labels[i]; ids32[i] = (uint32_t)ids64[i];
+            }
+            const float* xdev = nullptr;
+            CHECK(rows_to_device_f32(h, cnt, buf.data(), SSMI_F32, SSMI_HOST, &xdev));
+            CHECK(ivf_append_preassigned(h, cnt, xdev, lab.data(), ids32.data()));
+        }
+        S->persist_journal_rows += (long long)n;
+        pos = vec0 + n * (uint64_t)d * 4;
+    }
+    return 0;
+}
+
 }  // namespace
 extern "C" {
 
@@ -131,6 +244,11 @@ int ssmi_index_write(ssmi_index* h, const char* path) {
         }
     }
     if (fflush(f) != 0) return fail("write_index: flush failed for %s", path);
+    if (h->kind == SSMI_KIND_IVFFLAT) {
+        fclose(F.f); F.f = nullptr;
+        remove(journal_path(path).c_str());  // a full write supersedes the journal of the previous base file
+        record_full_state(h, path);
+    }
     return 0;
     });
 }
@@ -143,9 +261,19 @@ int ssmi_index_write(ssmi_index* h, const char* path) {
 int ssmi_index_write_append(ssmi_index* h, const char* path) {
     return guarded([&]() -> int {
     if (!h || !path) return fail("NULL argument");
-    if (h->kind != SSMI_KIND_FLAT) return ssmi_index_write(h, path);
     DeviceGuard g(h->device);
     quiesce(h);
+    if (h->kind != SSMI_KIND_FLAT) {
+        // IVF: the members gained since the last checkpoint go to "<path>.journal" (one record); the base file is
+        // rewritten only when this handle has no full state for `path`, the base file changed under it, or the
+        // journal has grown to half the base (then the next read would replay too much)
+        IvfState* S = st(h);
+        const bool same = S->persist_path == path && S->persist_base_ntotal >= 0 && (int)S->persist_size.size() == h->nlist &&
+                          file_bytes(path) == S->persist_base_bytes && h->ivf_ntotal >= S->persist_base_ntotal + S->persist_journal_rows;
+        const long long fresh_rows = h->ivf_ntotal - (same ? S->persist_base_ntotal + S->persist_journal_rows : 0);
+        if (!same || S->persist_journal_rows + fresh_rows > S->persist_base_ntotal / 2 + 65536) return ssmi_index_write(h, path);
+        return append_journal(h, path);
+    }
     const RowStore& R = h->rows;
     const long kHeader = 4 + 33;  // fourcc + header; then n_floats:u64, then the rows
     int64_t have = -1;
@@ -337,6 +465,13 @@ int ssmi_index_read(const char* path, int storage_dtype, int device, ssmi_index*
         got += n;
     }
     if (got != ntotal) return fail("read_index: lists hold %lld vectors, header says %lld", (long long)got, (long long)ntotal);
+    fclose(F.f); F.f = nullptr;
+    S->persist_path = path;
+    S->persist_base_ntotal = ntotal;
+    S->persist_base_bytes = file_bytes(path);
+    S->persist_journal_rows = 0;
+    CHECK(replay_journal(h, path, ntotal));
+    S->persist_size = S->size;
     guard.h = nullptr;
     *out = h;
     return 0;

@@ -433,7 +433,9 @@ class IndexIVFFlat(_IndexBase):
 
 def write_index(index: _IndexBase, path, incremental: bool = False) -> None:
     """Stand-in for faiss.write_index (core/index_manager.py:241).  incremental=True: if `path` already holds an
-    earlier state of this Flat index, only the rows added since are appended (same bytes as a full write)."""
+    earlier state of this index, only the vectors added since are written: a Flat index appends them to the file
+    (same bytes as a full write); an IVF index appends a record to `<path>.journal`, which read_index replays on
+    top of the base file (a full write, incremental=False, folds the journal back in and removes it)."""
     fn = index._lib.ssmi_index_write_append if incremental else index._lib.ssmi_index_write
     _lib.check(fn(index._handle(), os.fsencode(str(path))))
 

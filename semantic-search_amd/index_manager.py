@@ -236,7 +236,8 @@ class SemanticIndex:
     def save(self) -> None:
         """:238-242"""
         with self._lock:
-            # a Flat index that only grew since the last checkpoint appends its new rows (same file, O(new rows))
+            # an index that only grew since the last checkpoint writes its new rows only: Flat appends them to the
+            # file, IVF appends a record to vectors.faiss.journal (O(new rows) instead of O(N) per checkpoint)
             faiss.write_index(self._faiss_index, str(self.faiss_path), incremental=True)
             self._save_config()
             if self._training_buffer_size:
@@ -447,8 +448,12 @@ class SemanticIndex:
                 "needs_compaction": needs}
 
     def close(self) -> None:
-        """:1474-1477"""
+        """:1474-1477.  An IVF index that checkpointed incrementally leaves vectors.faiss.journal next to the base
+        file; closing folds it back in with one full write, so the file at rest is a plain, complete FAISS file."""
         self.save()
+        if Path(str(self.faiss_path) + ".journal").exists():
+            with self._lock:
+                faiss.write_index(self._faiss_index, str(self.faiss_path))
         self.db.close()
         self._faiss_index.close()
 

@@ -266,6 +266,70 @@ def test_incremental_write_is_byte_identical_to_full_write(ssa, tmp_path, storag
     assert a.read_bytes() == b.read_bytes()
 
 
+def test_ivf_incremental_checkpoints_journal(ssa, tmp_path):
+    """SURVEY.md 8f rank 4 for IVF: a checkpoint of a grown IVF index appends the new members to
+    vectors.faiss.journal instead of rewriting the base file (the reference rewrites everything every 10 batches,
+    core/index_manager.py:859-860 -> :241); read_index replays the journal; a full write folds it back in."""
+    import os
+    d, nlist = 96, 12
+    X = unit_rows(4000, d, 31)
+    C = unit_rows(nlist, d, 32)
+    ivf = ssa.IndexIVFFlat(ssa.IndexFlatIP(d), d, nlist, ssa.METRIC_INNER_PRODUCT)
+    ivf.set_centroids(C)
+    ivf.nprobe = 4
+    p, j = tmp_path / "vectors.faiss", tmp_path / "vectors.faiss.journal"
+    ivf.add(X[:3000])
+    ssa.write_index(ivf, p, incremental=True)                 # first checkpoint: full write
+    base = p.read_bytes()
+    assert not j.exists()
+    jsizes = []
+    done = 3000
+    for step in (16, 16, 160, 1, 0, 300):                     # the reference adds 16 vectors per batch
+        ivf.add(X[done:done + step]); done += step
+        ssa.write_index(ivf, p, incremental=True)
+        assert p.read_bytes() == base                         # the base file is not touched
+        jsizes.append(os.path.getsize(j) if j.exists() else 0)
+    rec = lambda n: 12 + n * (4 + 8 + d * 4)
+    assert jsizes == list(np.cumsum([32 + rec(16), rec(16), rec(160), rec(1), 0, rec(300)]))
+    Q = unit_rows(5, d, 33)
+    D0, I0 = ivf.search(Q, 10)
+    back = ssa.read_index(p)
+    assert back.ntotal == done == ivf.ntotal and back.nprobe == 4
+    np.testing.assert_array_equal(back.assignments(), ivf.assignments())
+    D1, I1 = back.search(Q, 10)
+    np.testing.assert_array_equal(I1, I0); np.testing.assert_array_equal(D1, D0)
+    # the reloaded index goes on journaling where the file stands
+    back.add(X[done:done + 50]); ivf.add(X[done:done + 50]); done += 50
+    ssa.write_index(back, p, incremental=True)
+    assert p.read_bytes() == base and os.path.getsize(j) == jsizes[-1] + rec(50)
+    # a torn tail (crash while appending) costs only the torn record
+    whole = j.read_bytes()
+    j.write_bytes(whole[:-7])
+    torn = ssa.read_index(p)
+    assert torn.ntotal == done - 50
+    j.write_bytes(whole)
+    # a full write folds the journal in: same bytes as a full write of the index that never left memory
+    full_a, full_b = tmp_path / "a.faiss", tmp_path / "b.faiss"
+    again = ssa.read_index(p)
+    ssa.write_index(again, full_a); ssa.write_index(ivf, full_b)
+    assert full_a.read_bytes() == full_b.read_bytes()
+    ssa.write_index(again, p)
+    assert not j.exists() and p.read_bytes() == full_b.read_bytes()
+    # a journal that belongs to another base file is ignored
+    j.write_bytes(whole)
+    assert ssa.read_index(p).ntotal == done
+    # the journal is bounded: once it holds more than half the base (+64k rows) the checkpoint rewrites the base
+    small = ssa.IndexIVFFlat(ssa.IndexFlatIP(d), d, nlist, ssa.METRIC_INNER_PRODUCT)
+    small.set_centroids(C)
+    small.add(X[:10])
+    sp, sj = tmp_path / "s.faiss", tmp_path / "s.faiss.journal"
+    ssa.write_index(small, sp, incremental=True)
+    big = unit_rows(70000, d, 34)
+    small.add(big)
+    ssa.write_index(small, sp, incremental=True)
+    assert not sj.exists() and ssa.read_index(sp).ntotal == 70010
+
+
 def test_search_multi_index_merges_like_the_node(ssa, tmp_path):
     from semantic_search_amd.index_manager import SemanticIndex, search_multi_index
     d = 64
