@@ -10,6 +10,18 @@
 // complete before the ticket is taken and read back with device-scope loads; a release/acquire
 // fence pair instead (an L2 write-back and invalidate per block) measured +18 us per launch.
 //
+// Why this is sound without a fence pair, and what guards it: (1) the list is published with agent-scope relaxed
+// atomic stores, which gfx950 emits as `global_store_dwordx2 ... sc1`: write-through, the bytes leave the CU and
+// the XCD's L2 (MI355X_MICROARCH.md, "stores of each flavour"); (2) the publishing wave drains them with an
+// inline-asm `s_waitcnt vmcnt(0)` (invisible to the compiler's wait-count pass, so it cannot be dropped or moved)
+// and only then - behind the workgroup barrier of tail_last_block - one lane takes the ticket with a returning
+// device-scope atomic add; (3) the block that drew the last ticket reads the lists with agent-scope relaxed atomic
+// loads = `global_load_dwordx2 ... sc1`, which bypass its L1 and are served by the memory side, after a workgroup
+// barrier behind the ticket.  This is the guide's "sc1 stores + drained counter add + sc1 loads" hand-off (one
+// lane of each storing workgroup adds to ONE counter, the workgroup whose add came last reads).  All three are
+// properties of the generated instructions, so tools/check_tail_merge.py asserts them on the assembly of every
+// kernel with a tail (tests/test_tail_merge_isa_cpu.py), and tools/soak_tail_merge.py soaks the behaviour.
+//
 // Stands in for the heap merge inside faiss.IndexFlatIP.search / IndexIVFFlat.search
 // (reference call site core/index_manager.py:371).
 #pragma once
