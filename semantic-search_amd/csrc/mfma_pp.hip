@@ -35,6 +35,10 @@
 #include <algorithm>
 #endif
 
+#ifndef SSMI_PP_PRIO
+#define SSMI_PP_PRIO 0  // 0: setprio(1) around every MFMA segment; 1: static priority for waves 4-7; 2: none
+#endif
+
 namespace ssmi {
 
 static constexpr int SLAB = 256 * 64;          // one operand slab: 16 KiB
@@ -160,6 +164,9 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
         if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier event behind
         STAMP(0)
 
+#if SSMI_PP_PRIO == 1
+        if (wm == 1) __builtin_amdgcn_s_setprio(1);  // static priority for the younger half, no per-segment flips
+#endif
         for (int p = 0; p < np; ++p) {
             const unsigned char* slab = smem + (p & (RING - 1)) * PHASE_LDS;
             // ---- LOAD segment (the partner group owns the matrix pipe meanwhile) ----
@@ -189,16 +196,23 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             // ---- MFMA segment ----
+#if SSMI_PP_PRIO == 0
             __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int m = 0; m < 8; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], b[n], acc[m][n], 0, 0, 0);
+#if SSMI_PP_PRIO == 0
             __builtin_amdgcn_s_setprio(0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
         }
+#if SSMI_PP_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (wm == 0) __builtin_amdgcn_s_barrier();  // realign the two groups
         STAMP(1)
 

@@ -161,13 +161,14 @@ class SemanticIndex:
 
     def __init__(self, index_name: str, embedding_dim: int = 4096, index_type: str = "flat",
                  base_path: Optional[Path] = None, storage: str = "f32", device: Optional[int] = None,
-                 check_files_exist: bool = False):
+                 check_files_exist: bool = True):
         self.index_name = index_name
         self.embedding_dim = embedding_dim
         self.index_type_str = index_type
         self._engine_opts = {"storage": storage}
         if device is not None:
             self._engine_opts["device"] = device
+        # the reference drops hits whose file has disappeared since indexing (:389); False skips the stat per hit
         self._check_files_exist = check_files_exist
         self.index_path = get_index_path(index_name, Path(base_path) if base_path else None)
         self.faiss_path = self.index_path / "vectors.faiss"     # core/config.py:153-155

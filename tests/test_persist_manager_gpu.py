@@ -159,7 +159,7 @@ def test_semantic_index_lifecycle(ssa, tmp_path):
     from semantic_search_amd.index_manager import SemanticIndex
     d = 96
     X = unit_rows(1200, d, 9)
-    si = SemanticIndex("photos", embedding_dim=d, index_type="ivf-flat", base_path=tmp_path)
+    si = SemanticIndex("photos", embedding_dim=d, check_files_exist=False, index_type="ivf-flat", base_path=tmp_path)
     assert si.get_index_type() == "ivf_flat"
     ids = []
     for s in range(0, 1200, 16):                  # reference batches: 16 images (core/config.py:59)
@@ -185,7 +185,7 @@ def test_semantic_index_lifecycle(ssa, tmp_path):
     si.save()
     assert si.faiss_path.exists() and si.config_path.exists()
     # reload from disk
-    si2 = SemanticIndex("photos", embedding_dim=4096, base_path=tmp_path)
+    si2 = SemanticIndex("photos", embedding_dim=4096, check_files_exist=False, base_path=tmp_path)
     assert si2.embedding_dim == d and si2.get_index_type() == "ivf_flat" and si2._faiss_index.ntotal == 1200
     # rebuild to flat fails without a direct map (reference behaviour), works after make_direct_map
     assert si2.rebuild("flat")["success"] is False
@@ -213,13 +213,13 @@ def test_training_buffer_survives_save_and_reload(ssa, tmp_path):
     from semantic_search_amd.index_manager import SemanticIndex
     d = 64
     X = unit_rows(1100, d, 19)
-    si = SemanticIndex("buf", embedding_dim=d, index_type="ivf_flat", base_path=tmp_path)
+    si = SemanticIndex("buf", embedding_dim=d, check_files_exist=False, index_type="ivf_flat", base_path=tmp_path)
     ids = si.add_vectors(X[:600], [f"/i/{i}" for i in range(600)], [""] * 600, [(0.0, 0)] * 600)
     assert ids == list(range(600)) and si._faiss_index.ntotal == 0 and si._training_buffer_size == 600
     si.save()
     assert si.training_buffer_path.exists()
     si.close()
-    si2 = SemanticIndex("buf", embedding_dim=d, index_type="ivf_flat", base_path=tmp_path)
+    si2 = SemanticIndex("buf", embedding_dim=d, check_files_exist=False, index_type="ivf_flat", base_path=tmp_path)
     assert si2._training_buffer_size == 600 and not si2._faiss_index.is_trained
     ids = si2.add_vectors(X[600:], [f"/i/{i}" for i in range(600, 1100)], [""] * 500, [(0.0, 0)] * 500)
     assert ids == list(range(600, 1100))
@@ -334,8 +334,8 @@ def test_search_multi_index_merges_like_the_node(ssa, tmp_path):
     from semantic_search_amd.index_manager import SemanticIndex, search_multi_index
     d = 64
     X = unit_rows(600, d, 21)
-    a = SemanticIndex("a", embedding_dim=d, base_path=tmp_path)
-    b = SemanticIndex("b", embedding_dim=d, base_path=tmp_path)
+    a = SemanticIndex("a", embedding_dim=d, check_files_exist=False, base_path=tmp_path)
+    b = SemanticIndex("b", embedding_dim=d, check_files_exist=False, base_path=tmp_path)
     a.add_vectors(X[:300], [f"/a/{i}.jpg" for i in range(300)], [f"/ta/{i}.jpg" for i in range(300)], [(1.0, 1)] * 300)
     b.add_vectors(X[300:], [f"/b/{i}.jpg" for i in range(300)], [f"/tb/{i}.jpg" for i in range(300)], [(1.0, 1)] * 300)
     q = X[310]
@@ -345,3 +345,10 @@ def test_search_multi_index_merges_like_the_node(ssa, tmp_path):
     assert merged[0].file_path == "/b/10.jpg"
     assert len(search_multi_index([a, b], q, top_k=5, normalize_scores=False, min_score=0.99)) == 1
     a.close(); b.close()
+    # by default hits whose file no longer exists are dropped, like the reference does (core/index_manager.py:389)
+    real = tmp_path / "real.jpg"
+    real.write_bytes(b"x")
+    c = SemanticIndex("c", embedding_dim=d, base_path=tmp_path)
+    c.add_vectors(X[:2], ["/gone/0.jpg", str(real)], ["", ""], [(0.0, 0)] * 2)
+    assert [r.file_path for r in c.search(X[0], top_k=2)] == [str(real)]
+    c.close()
