@@ -148,7 +148,9 @@ int ssmi_static_scratch_bytes(size_t* out);
  * sets on the device, each (nq,k) row-major; set l starts at D_lists +
  * l*d_list_stride and I_lists + l*i_list_stride (strides in elements, so one
  * all-gathered buffer holding both scores and ids can be merged in place);
- * output is the (nq,k) top-k of their union, same ordering rules. */
+ * output is the (nq,k) top-k of their union, same ordering rules.  Ids (after every shard's id_offset) must stay
+ * below 2^32-1: the merge orders 64-bit (score, id) keys with 32 bits of id (sharded.py checks the global row count
+ * when the shards agree on their offsets). */
 int ssmi_topk_merge(int device, int nlists, int64_t nq, int k,
                     const float* D_lists, int64_t d_list_stride,
                     const int64_t* I_lists, int64_t i_list_stride,
