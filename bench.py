@@ -339,7 +339,7 @@ def run_ivf(args, D, emit=True, with_cpu=True):
         ivf = ssa.IndexIVFFlat(ssa.IndexFlatIP(d, storage="f16"), d, nlist, ssa.METRIC_INNER_PRODUCT, storage="f16")
         flat = ssa.IndexFlatIP(d, storage="f16")
     ntrain = min(n, 256 * nlist)
-    xt = rows(ntrain) if rank == 0 else None
+    xt = ivf_rows_factory(args, dev, n, seed=99)(ntrain) if rank == 0 else None
     D.fence(); t0 = time.perf_counter()
     (ivf_s if sharded else ivf).train(xt)
     D.fence(); t_train = time.perf_counter() - t0
@@ -354,8 +354,15 @@ def run_ivf(args, D, emit=True, with_cpu=True):
         else:
             ivf.add(x)
         torch.cuda.synchronize(); t_add += time.perf_counter() - t0
-        flat.add(x)
-    del x
+        if os.environ.get("SSMI_BENCH_DEBUG") and (s0 // 65536) % 20 == 19:
+            print("[ivf add] chunks to %d: %.3f s so far, mem free %.1f GiB" % (s0 // 65536 + 1, t_add, torch.cuda.mem_get_info()[0] / 2**30), file=sys.stderr, flush=True)
+    # the Flat twin (ground truth of the recall figure) takes the same rows in a second pass of the same generator:
+    # built beside the IVF index it doubles the memory in use while add() is being timed, and hipMalloc of the 1 GiB
+    # storage segments then takes 10-30 ms instead of under one (measured: tools/time_ivf_add.py, WITH_FLAT=1)
+    rows = ivf_rows_factory(args, dev, n, seed=1234 + rank)
+    for s0 in range(0, n_local, 65536):
+        flat.add(rows(min(65536, n_local - s0), row0 + s0))
+    x = None
     t_add = D.max_over_ranks(t_add)
     if sharded:
         flat_s.finalize(device=dev)

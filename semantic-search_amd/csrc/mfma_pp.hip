@@ -45,7 +45,11 @@ static constexpr int SLAB = 256 * 64;          // one operand slab: 16 KiB
 static constexpr int PHASE_LDS = 2 * SLAB;     // X slab + Q slab
 static constexpr int RING = 4;
 
-template <int R>
+// ARGMAX (k == 1: IVF centroid assignment, K5): no threshold, candidate buffers or folds at all - every lane keeps
+// the best (score, row) of each of its four query columns across the row tiles of the slice, the four lanes and two
+// waves that share a column combine once at the end.  Assignment batches have no score structure to prune with
+// (every centroid scores alike on unclustered rows), so the filter path spent its time on survivors there.
+template <int R, bool ARGMAX = false>
 __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* thr_l = reinterpret_cast<float*>(smem + RING * PHASE_LDS);
@@ -141,6 +145,10 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
 #define STAMP(i)
 #endif
     unsigned tiles_done = 0;
+    float best_s[4];
+    uint32_t best_r[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { best_s[n] = -__builtin_inff(); best_r[n] = 0xFFFFFFFFu; }
     const size_t tile_stride = (size_t)TM * (size_t)ld * 2;
     for (long long row0 = r_begin; row0 < r_end; row0 += TM) {
         // The ring runs on ACROSS row tiles when the next tile is whole and lies in the same storage segment
@@ -229,8 +237,26 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
         }
 
         STAMP(2)
-        // ---- epilogue: threshold filter, survivors -> candidate buffers ----
         const long long left = r_end - row0;
+        if constexpr (ARGMAX) {
+            // ---- epilogue, k == 1: running maximum per query column, in registers ----
+            const int rows_valid = left >= TM ? TM : (int)left;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int rr = wm * 128 + m * 16 + fq * 4 + i;
+                        const float sc = acc[m][n][i];
+                        // a lane meets its rows in ascending order: strict > keeps the lowest id among equal scores
+                        const bool take = sc > best_s[n] && rr < rows_valid;
+                        best_s[n] = take ? sc : best_s[n];
+                        best_r[n] = take ? (uint32_t)(row0 + rr) : best_r[n];
+                    }
+            continue;
+        }
+        // ---- epilogue: threshold filter, survivors -> candidate buffers ----
         if (left >= TM) filter_tile<8, 4, true>(acc, wm * 128, wn * 64, frow, fq, row0, TM, cand, thr_l, cnt_l, flag_l);
         else filter_tile<8, 4, false>(acc, wm * 128, wn * 64, frow, fq, row0, (int)left, cand, thr_l, cnt_l, flag_l);
         STAMP(3)
@@ -271,6 +297,26 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
 
     // ---- end of slice: fold what is left; the k-list is the partial result ----
     __syncthreads();
+    if constexpr (ARGMAX) {
+        skey_t* red = reinterpret_cast<skey_t*>(smem);  // the ring is idle: every wave is past its last fragment read
+        skey_t key[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            key[n] = best_r[n] == 0xFFFFFFFFu ? 0 : make_key(best_s[n], best_r[n]);
+            key[n] = kmax(key[n], xor_lane64<16>(key[n]));   // the four lanes (fq) that hold rows of this column
+            key[n] = kmax(key[n], xor_lane64<32>(key[n]));
+            if (wm == 1 && fq == 0) red[wn * 64 + n * 16 + frow] = key[n];
+        }
+        __syncthreads();
+        if (wm == 0 && fq == 0) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int ql = wn * 64 + n * 16 + frow;
+                if (q0 + ql < P.nq) P.partial[((size_t)(q0 + ql) * P.nslices + slice) * P.k] = kmax(key[n], red[ql]);
+            }
+        }
+        return;
+    }
     fold_queries<R>(wave, q0, P, slice, cand, thr_l, cnt_l, kept_l);
 }
 
@@ -290,6 +336,12 @@ hipError_t launch_flat_mfma_pp(const MfmaParams& P_in, int r, int grid, size_t l
         hipLaunchKernelGGL((flat_mfma_pp_kernel<RR>), dim3(grid), dim3(512), lds, s, P);               \
         break;                                                                                          \
     }
+    if (P.k == 1) {  // nearest-centroid assignment and any other top-1 batch
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(flat_mfma_pp_kernel<1, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((flat_mfma_pp_kernel<1, true>), dim3(grid), dim3(512), lds, s, P);
+    } else
     switch (r) {
         LAUNCH_R(1) LAUNCH_R(2) LAUNCH_R(4) LAUNCH_R(8) LAUNCH_R(16)
         default: return hipErrorInvalidValue;

@@ -128,3 +128,29 @@ def test_wide_kernel_best_rows_in_one_slice(ssa, k):
         assert ok, msg
         assert (I[:, :min(k, 100)] < 600).all()
     index.close()
+
+
+@pytest.mark.parametrize("n,d,nq", [(4096, 1024, 300), (5000, 512, 1000), (70001, 256, 260), (300, 4096, 513)])
+def test_top1_batches_take_the_argmax_epilogue(ssa, n, d, nq):
+    """k == 1 on the 256-query MFMA kernel (IVF centroid assignment, K5): the running-maximum epilogue must give the
+    oracle's top-1 on the fp16-rounded operands - several slices, a ragged last row tile, more query tiles than CUs -
+    and the lowest id among exactly equal rows."""
+    import numpy as np
+    from conftest import unit_rows
+    from oracle import flat_ip
+    X = unit_rows(n, d, 11)
+    X[n // 2] = X[7]; X[n - 1] = X[7]                       # three identical rows: ties go to the lowest id
+    Q = unit_rows(nq, d, 12)
+    Q[5] = X[7]
+    index = ssa.IndexFlatIP(d, storage="f16")
+    index.add(X)
+    D, I = index.search(Q, 1)
+    assert index.last_kernel() == "flat_mfma_pp_kernel" and index.last_timing()["last_path"] == 1
+    Xh, Qh = X.astype(np.float16).astype(np.float32), Q.astype(np.float16).astype(np.float32)
+    Dr, Ir = flat_ip.search(Xh, Qh, 1)
+    ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xh, Qh, rtol=1e-5, tie_rtol=1e-5)
+    assert ok, msg
+    assert I[5, 0] == 7
+    D2, I2 = index.search(Q, 2)                             # and agrees with the first column of the general path
+    np.testing.assert_array_equal(I2[:, 0], I[:, 0]); np.testing.assert_array_equal(D2[:, 0], D[:, 0])
+    index.close()
