@@ -184,6 +184,19 @@ __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
             __syncthreads();  // drains the candidate stores (and the row stream, once per compaction)
             for (int ql = wave; ql < N128_TN; ql += 8)
                 if (ql < P.nq) compact_query<R>(ql, ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
+            // Share the thresholds between the slices (one per CU, a few thousand rows each: a slice's own k-th score
+            // stays weak to the end): the k-th score of ANY slice bounds the final k-th score from below, so every
+            // slice filters with the highest one reached anywhere.  Same exchange as the 256-query kernel: one
+            // atomic max per query and fold, the wave's 16 queries in one round trip.
+            if (P.gthr && lane < 16) {
+                const int ql = wave + 8 * lane;
+                if (ql < P.nq) {
+                    const float t = thr_l[ql];
+                    const unsigned mine = (t > SSMI_NEG_MAX) ? f32_to_ord(t) : 0u;
+                    const unsigned seen = atomicMax(&P.gthr[ql], mine);
+                    if (seen > mine) thr_l[ql] = ord_to_f32(seen);
+                }
+            }
             __syncthreads();
             if (tid == 0) *flag_l = 0;
             // the loads of the register ring were drained with everything else, which the counted waits
