@@ -389,13 +389,28 @@ def run_ivf(args, D, emit=True, with_cpu=True):
     probed_rows = float(np.mean(rows_s))
     algo_bytes = probed_rows * d * 2
     scan_ms_sample = float(np.mean(ms_s))
+    small = {}
+    for B in (8, 32):   # small batches still take the per-query scan: nq x (512/nq) blocks in one launch
+        el = D.timed(lambda i: search(Q[(i * B) % 960:(i * B) % 960 + B]), 50, 3)
+        small["batch_%d_qps" % B] = B * 50 / el
     search(Q)  # warm the batched path
     t_b = D.timed(lambda i: search(Q), 1, 0)
     batched_kernel = ivf.last_kernel()
     Q4 = qrows(4096)
     search(Q4)
     t_b4 = D.timed(lambda i: search(Q4), 1, 0)
-    del Q4
+    # batched roofline ("the roofline fraction uses the union" of the probed lists, what must minimally be
+    # read): the lists a batch probes, recomputed here from the index's centroids, times this rank's list sizes
+    Cdev = torch.from_numpy(ivf.get_centroids()).to(dev)
+    ls_dev = torch.from_numpy(ls.astype(np.int64)).to(dev)
+
+    def union_bytes(Qb):
+        probed = torch.zeros((nlist,), dtype=torch.bool, device=dev)
+        for s0 in range(0, Qb.shape[0], 1024):
+            probed[torch.topk(Qb[s0:s0 + 1024] @ Cdev.T, min(nprobe, nlist), dim=1).indices.reshape(-1)] = True
+        return float((ls_dev * probed).sum().item()) * d * 2
+    ub1000, ub4096 = union_bytes(Q), union_bytes(Q4)
+    del Q4, Cdev
     Di, Ii = search(Q)
     Df, If = (flat_s.search(Q, k) if sharded else flat.search(Q, k))
     torch.cuda.synchronize()
@@ -418,7 +433,11 @@ def run_ivf(args, D, emit=True, with_cpu=True):
                      "kernel": scan_kernel, "kernel_avg_ms": scan_ms_sample},
         "extra": {"train_s": t_train, "add_s": t_add, "add_vectors_per_s": n / t_add,
                   "list_sizes_rank0": {"min": int(ls.min()), "median": float(np.median(ls)), "max": int(ls.max())},
-                  "batch_1000_qps": 1000 / t_b, "batch_4096_qps": 4096 / t_b4, "batched_kernel": batched_kernel,
+                  **small, "batch_1000_qps": 1000 / t_b, "batch_4096_qps": 4096 / t_b4, "batched_kernel": batched_kernel,
+                  "batch_1000_hbm_frac_end_to_end": ub1000 / t_b / 1e9 / HBM_PEAK_GBS,
+                  "batch_4096_hbm_frac_end_to_end": ub4096 / t_b4 / 1e9 / HBM_PEAK_GBS,
+                  "batched_roofline_note": "bytes = rows of the UNION of the lists the batch probes (rank 0's share) x d x 2 B, "
+                                           "over the whole search call (coarse step, probe-table inversion, list scan, merge)",
                   "recall_at_%d_vs_flat" % k: recall,
                   "recall_note": "1000 queries; ground truth = IndexFlatIP (f16 rows) over the same vectors"},
     }
