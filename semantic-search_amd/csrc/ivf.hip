@@ -54,19 +54,47 @@ __global__ void rows_to_f32_kernel(const S* __restrict__ src, int d, int ld, flo
     for (int e = threadIdx.x; e < ld; e += blockDim.x) out[i * ld + e] = (e < d) ? (float)src[i * d + e] : 0.f;
 }
 
-// rows (n,ld) fp32 -> slot store rows dst_slot[i]; records the id of each slot
+// rows (n,ld) fp32 -> slot store rows dst_slot[i] (negative: the row is not stored); records the id of each slot
 template <typename T>
 __global__ void scatter_rows_kernel(const float* __restrict__ src, int ld, const int* __restrict__ dst_slot,
                                     void* const* segs, int seg_shift, uint32_t* __restrict__ slot_ids, uint32_t id0,
-                                    const uint32_t* __restrict__ ids, const int* __restrict__ src_idx) {
+                                    const uint32_t* __restrict__ ids) {
     const size_t i = blockIdx.x;
-    const size_t si = src_idx ? (size_t)src_idx[i] : i;
     const long long slot = dst_slot[i];
+    if (slot < 0) return;
     const long long mask = (1ll << seg_shift) - 1;
     T* dst = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(segs[slot >> seg_shift]) +
                                   (size_t)(slot & mask) * (size_t)ld * sizeof(T));
-    for (int e = threadIdx.x; e < ld; e += blockDim.x) dst[e] = (T)src[si * ld + e];
+    for (int e = threadIdx.x; e < ld; e += blockDim.x) dst[e] = (T)src[i * ld + e];
     if (threadIdx.x == 0) slot_ids[slot] = ids ? ids[i] : id0 + (uint32_t)i;
+}
+
+// list-sharded add: vectors whose list belongs to another rank are left out of the bucketing
+__global__ void mask_shard_labels_kernel(int64_t* __restrict__ labels, long long n, int nlist, int shard, int nshards) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t l = labels[i];
+    if (l >= 0 && l < nlist && (int)(l % nshards) != shard) labels[i] = kBucketSkip;
+}
+
+// int32 labels from the host -> the int64 labels the bucketing reads
+__global__ void widen_labels_kernel(const int* __restrict__ in, long long n, int64_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+// slot of every new vector from its rank among the batch's vectors of its list.  fill[l] = {first free slot in the
+// list's last page, free slots there, first of the consecutive pages this add gave the list}
+__global__ void slots_from_rank_kernel(const int64_t* __restrict__ labels, const int* __restrict__ rank, long long n,
+                                       const int* __restrict__ fill, int* __restrict__ dst_slot) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = rank[i];
+    if (r < 0) { dst_slot[i] = -1; return; }
+    const int* f = fill + 3 * (size_t)labels[i];
+    const int room = f[1];
+    const int over = r - room;
+    dst_slot[i] = over < 0 ? f[0] + r : (f[2] + (over >> kPageShift)) * kPageRows + (over & (kPageRows - 1));
 }
 
 // K6: centroid l = mean of its members (fixed summation order -> deterministic)
@@ -507,15 +535,26 @@ int rows_to_device_f32(ssmi_index* h, int64_t n, const void* x, int src_dtype, i
     return 0;
 }
 
-// nearest centroid (max inner product) of n device rows -> host labels
-static int assign_to_centroids(ssmi_index* h, int64_t n, const float* xdev, std::vector<int>* labels) {
+// K5: nearest centroid (max inner product) of n device rows -> int64 labels on the device (default: workspace 7)
+static int assign_to_centroids(ssmi_index* h, int64_t n, const float* xdev, int64_t** labels_dev, int64_t* into = nullptr) {
     IvfState* S = st(h);
     const RowStore& C = (n >= 9 && (S->cent16.ld % 64) == 0) ? S->cent16 : S->cent32;
     CHECK(ensure_ws(h, 6, (size_t)n * 4));
-    CHECK(ensure_ws(h, 7, (size_t)n * 8));
-    CHECK(store_search(h, C, n, xdev, 1, (float*)h->ws[6], (int64_t*)h->ws[7], 0, h->stream, false));
+    if (!into) {
+        CHECK(ensure_ws(h, 7, (size_t)n * 8));
+        into = (int64_t*)h->ws[7];
+    }
+    CHECK(store_search(h, C, n, xdev, 1, (float*)h->ws[6], into, 0, h->stream, false));
+    if (labels_dev) *labels_dev = into;
+    return 0;
+}
+
+// ... and read back (ssmi_index_assign)
+static int assign_to_centroids_host(ssmi_index* h, int64_t n, const float* xdev, std::vector<int>* labels) {
+    int64_t* dev = nullptr;
+    CHECK(assign_to_centroids(h, n, xdev, &dev));
     std::vector<int64_t> tmp((size_t)n);
-    HIPCHECK(hipMemcpyAsync(tmp.data(), h->ws[7], (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipMemcpyAsync(tmp.data(), dev, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
     labels->resize((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
@@ -589,41 +628,36 @@ int ivf_train(ssmi_index* h, int64_t n, const float* x, int mem_kind) {
     CHECK(install_centroids(h, C0, SSMI_DEVICE));
     h->trained = false;
 
+    // per iteration: K5 labels -> K7 buckets (perm, off) -> K6 means, all on the device; the host only sees the
+    // nlist list sizes (for the empty-cluster fix)
     int *d_perm = nullptr, *d_off = nullptr;
+    int64_t* d_labels = nullptr;
     HIPCHECK(hipMalloc((void**)&d_perm, (size_t)nt * 4));
     struct Free3 { int* p; ~Free3() { if (p) (void)hipFree(p); } } freeP{d_perm};
     HIPCHECK(hipMalloc((void**)&d_off, (size_t)(nlist + 1) * 4));
     struct Free4 { int* p; ~Free4() { if (p) (void)hipFree(p); } } freeO{d_off};
+    HIPCHECK(hipMalloc((void**)&d_labels, (size_t)nt * 8));
+    struct Free5 { int64_t* p; ~Free5() { if (p) (void)hipFree(p); } } freeL{d_labels};
+    CHECK(ensure_ws(h, 15, ivf_bucket_ws_bytes(nt, nlist)));
 
-    std::vector<int> labels, off((size_t)nlist + 1), order((size_t)nt), cursor((size_t)nlist);
+    std::vector<int> count((size_t)nlist + 1);
     for (int it = 0; it < S->niter; ++it) {
-        // K5: assignment = nearest (max inner product) centroid, in chunks that bound the query workspace
-        labels.clear();
-        std::vector<int> part;
-        const int64_t chunk = 1 << 16;
-        for (int64_t b = 0; b < nt; b += chunk) {
-            const int64_t cnt = std::min(chunk, nt - b);
-            CHECK(assign_to_centroids(h, cnt, X + (size_t)b * ld, &part));
-            labels.insert(labels.end(), part.begin(), part.end());
-        }
-        // counting sort of the points by label (stable -> fixed summation order)
-        std::fill(off.begin(), off.end(), 0);
-        for (int64_t i = 0; i < nt; ++i) off[labels[i] + 1]++;
-        for (int l = 0; l < nlist; ++l) off[l + 1] += off[l];
-        std::copy(off.begin(), off.end() - 1, cursor.begin());
-        for (int64_t i = 0; i < nt; ++i) order[cursor[labels[i]]++] = (int)i;
-        HIPCHECK(hipMemcpyAsync(d_perm, order.data(), (size_t)nt * 4, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(hipMemcpyAsync(d_off, off.data(), (size_t)(nlist + 1) * 4, hipMemcpyHostToDevice, h->stream));
+        const int64_t chunk = 1 << 16;  // bounds the query workspace of the assignment
+        for (int64_t b = 0; b < nt; b += chunk)
+            CHECK(assign_to_centroids(h, std::min(chunk, nt - b), X + (size_t)b * ld, nullptr, d_labels + b));
+        const int* d_total = nullptr;
+        HIPCHECK(launch_ivf_bucket(d_labels, nt, nlist, h->ws[15], d_off, d_perm, nullptr, &d_total, h->stream));
         hipLaunchKernelGGL(centroid_update_kernel, dim3(nlist), dim3(256), 0, h->stream, X, ld, d_perm, d_off,
                            (void* const*)S->cent32.d_segs, S->cent32.seg_shift, (void* const*)S->cent16.d_segs,
                            S->cent16.seg_shift);
         HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpyAsync(count.data(), d_total, (size_t)(nlist + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        if (count[nlist]) return fail("internal: centroid assignment produced a list outside [0, %d)", nlist);
         // empty clusters: split the currently largest cluster (deterministic variant of FAISS' fix)
-        std::vector<int> count((size_t)nlist);
-        for (int l = 0; l < nlist; ++l) count[l] = off[l + 1] - off[l];
         for (int l = 0; l < nlist; ++l) {
             if (count[l] != 0) continue;
-            const int big = (int)(std::max_element(count.begin(), count.end()) - count.begin());
+            const int big = (int)(std::max_element(count.begin(), count.end() - 1) - count.begin());
             if (count[big] < 2) break;
             hipLaunchKernelGGL(split_centroid_kernel, dim3(1), dim3(256), 0, h->stream, ld, (void* const*)S->cent32.d_segs,
                                S->cent32.seg_shift, (void* const*)S->cent16.d_segs, S->cent16.seg_shift, l, big,
@@ -688,79 +722,124 @@ static int ensure_slots(ssmi_index* h, long long npages) {
     return 0;
 }
 
-// append vectors (on the device as (n, ld) fp32) to given lists; ids == nullptr: sequential ids from ntotal.
+// append vectors (on the device as (n, ld) fp32) to the lists their labels name (int64 on the device; kBucketSkip
+// leaves a vector out).  Vector i takes the id ids_dev[i], or id0 + i.  K7 on the device ranks every vector inside
+// its list; the host sees the nlist per-list counts, gives every list its pages (consecutive numbers per list and
+// add) and hands back three ints per list from which a kernel derives every vector's slot.
 // The host-side list state (sizes, page tables, direct map) is committed only when every step that can fail
 // (slot store growth, workspace, launches) has succeeded; a failed add leaves the index as it was.
-int ivf_append_preassigned(ssmi_index* h, int64_t n, const float* xdev, const int* labels, const uint32_t* ids_host,
-                           const int* src_idx_host) {
+static int ivf_append_labelled(ssmi_index* h, int64_t n, const float* xdev, const int64_t* labels_dev, uint32_t id0,
+                               const uint32_t* ids_dev, bool sequential_ids, int64_t* n_added) {
+    if (n_added) *n_added = 0;
     if (n == 0) return 0;
     IvfState* S = st(h);
-    std::vector<int> dst((size_t)n);
-    std::vector<unsigned char> pushed((size_t)n, 0);
+    const int nlist = h->nlist;
+    // workspace 15: [K7 tables][off nlist+1][fill 3*nlist]; workspace 9: [rank n][slot n]
+    const size_t bucket_bytes = (ivf_bucket_ws_bytes(n, nlist) + 255) & ~(size_t)255;
+    CHECK(ensure_ws(h, 15, bucket_bytes + ((size_t)nlist * 4 + 1) * 4));
+    CHECK(ensure_ws(h, 9, (size_t)n * 8));
+    int* d_off = (int*)((char*)h->ws[15] + bucket_bytes);
+    int* d_fill = d_off + nlist + 1;
+    int* d_rank = (int*)h->ws[9];
+    int* d_slot = d_rank + n;
+    const int* d_total = nullptr;
+    HIPCHECK(launch_ivf_bucket(labels_dev, n, nlist, h->ws[15], d_off, nullptr, d_rank, &d_total, h->stream));
+    std::vector<int> count((size_t)nlist + 1);
+    HIPCHECK(hipMemcpyAsync(count.data(), d_total, (size_t)(nlist + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (count[nlist]) return fail("add: a vector names a list outside [0, %d)", nlist);
+
+    struct Undo { int list; int new_pages; long long old_size; };
+    std::vector<Undo> undo;
+    std::vector<int> fill((size_t)nlist * 3, 0);
     const size_t dm_size0 = S->direct_map.size();
-    for (int64_t i = 0; i < n; ++i) {
-        const int l = labels[i];
+    const long long npages0 = S->npages;
+    long long added = 0;
+    for (int l = 0; l < nlist; ++l) {
+        const int c = count[l];
+        if (!c) continue;
         const long long pos = S->size[l];
-        if ((pos & (kPageRows - 1)) == 0) { S->pages[l].push_back((int)S->npages++); pushed[i] = 1; }
-        const long long slot = (long long)S->pages[l][pos >> kPageShift] * kPageRows + (pos & (kPageRows - 1));
-        dst[i] = (int)slot;
-        S->size[l] = pos + 1;
-        if (S->has_direct_map && !ids_host) S->direct_map.push_back(slot);
+        const int in_page = (int)(pos & (kPageRows - 1));
+        const int room = in_page ? kPageRows - in_page : 0;
+        const int new_pages = c > room ? (c - room + kPageRows - 1) >> kPageShift : 0;
+        fill[(size_t)l * 3 + 0] = room ? S->pages[l].back() * kPageRows + in_page : 0;
+        fill[(size_t)l * 3 + 1] = room;
+        fill[(size_t)l * 3 + 2] = (int)S->npages;
+        undo.push_back({l, new_pages, pos});
+        for (int p = 0; p < new_pages; ++p) S->pages[l].push_back((int)(S->npages + p));
+        S->npages += new_pages;
+        S->size[l] = pos + c;
+        added += c;
     }
     auto rollback = [&]() {
-        for (int64_t i = n - 1; i >= 0; --i) {
-            const int l = labels[i];
-            S->size[l] -= 1;
-            if (pushed[i]) { S->pages[l].pop_back(); S->npages--; }
+        for (const Undo& u : undo) {
+            S->size[u.list] = u.old_size;
+            S->pages[u.list].resize(S->pages[u.list].size() - (size_t)u.new_pages);
         }
+        S->npages = npages0;
         S->direct_map.resize(dm_size0);
     };
     auto body = [&]() -> int {
         if (S->npages * kPageRows >= (1ll << 31)) return fail("IVF slot store would exceed 2^31 slots");
         CHECK(ensure_slots(h, S->npages));
-        CHECK(ensure_ws(h, 9, (size_t)n * 12));
-        HIPCHECK(hipMemcpyAsync(h->ws[9], dst.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-        const uint32_t* ids_dev = nullptr;
-        const int* src_idx_dev = nullptr;
-        if (ids_host) {
-            ids_dev = (const uint32_t*)((char*)h->ws[9] + (size_t)n * 4);
-            HIPCHECK(hipMemcpyAsync((void*)ids_dev, ids_host, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-        }
-        if (src_idx_host) {
-            src_idx_dev = (const int*)((char*)h->ws[9] + (size_t)n * 8);
-            HIPCHECK(hipMemcpyAsync((void*)src_idx_dev, src_idx_host, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-        }
+        HIPCHECK(hipMemcpyAsync(d_fill, fill.data(), fill.size() * 4, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(slots_from_rank_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, labels_dev,
+                           (const int*)d_rank, (long long)n, (const int*)d_fill, d_slot);
+        HIPCHECK(hipGetLastError());
         const RowStore& R = h->rows;
         if (R.dtype == SSMI_F32)
-            hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)h->ws[9],
-                               (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, (uint32_t)h->ivf_ntotal, ids_dev, src_idx_dev);
+            hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)d_slot,
+                               (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, id0, ids_dev);
         else
-            hipLaunchKernelGGL((scatter_rows_kernel<__half>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)h->ws[9],
-                               (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, (uint32_t)h->ivf_ntotal, ids_dev, src_idx_dev);
+            hipLaunchKernelGGL((scatter_rows_kernel<__half>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)d_slot,
+                               (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, id0, ids_dev);
         HIPCHECK(hipGetLastError());
         if (h->has_shadow && R.dtype == SSMI_F32) {
             // the fp16 shadow of the slot store (built by the first batched search, see ivf_search) follows every add
             RowStore& H = h->shadow16;
             CHECK(H.reserve(R.nrows, h->stream));
-            hipLaunchKernelGGL((scatter_rows_kernel<__half>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)h->ws[9],
-                               (void* const*)H.d_segs, H.seg_shift, S->d_slot_ids, (uint32_t)h->ivf_ntotal, ids_dev, src_idx_dev);
+            hipLaunchKernelGGL((scatter_rows_kernel<__half>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)d_slot,
+                               (void* const*)H.d_segs, H.seg_shift, S->d_slot_ids, id0, ids_dev);
             HIPCHECK(hipGetLastError());
             H.nrows = R.nrows;
+        }
+        if (S->has_direct_map && sequential_ids) {  // id -> slot on the host: the one per-vector read-back
+            std::vector<int> slots((size_t)n);
+            HIPCHECK(hipMemcpyAsync(slots.data(), d_slot, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(hipStreamSynchronize(h->stream));
+            for (int64_t i = 0; i < n; ++i) S->direct_map.push_back(slots[(size_t)i]);
         }
         HIPCHECK(hipStreamSynchronize(h->stream));
         return 0;
     };
     if (body()) { rollback(); return 1; }
-    h->ivf_ntotal += n;
+    h->ivf_ntotal += added;
     S->csr_dirty = true;
+    if (n_added) *n_added = added;
     return 0;
+}
+
+// the same for labels and ids held by the host (file reader, journal replay, routed add)
+int ivf_append_preassigned(ssmi_index* h, int64_t n, const float* xdev, const int* labels, const uint32_t* ids_host) {
+    if (n == 0) return 0;
+    // workspace 7: [labels int64 n][labels int32 n][ids n]
+    CHECK(ensure_ws(h, 7, (size_t)n * 16));
+    int64_t* lab64 = (int64_t*)h->ws[7];
+    int* lab32 = (int*)(lab64 + n);
+    uint32_t* ids_dev = ids_host ? (uint32_t*)(lab32 + n) : nullptr;
+    HIPCHECK(hipMemcpyAsync(lab32, labels, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    if (ids_host) HIPCHECK(hipMemcpyAsync(ids_dev, ids_host, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(widen_labels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const int*)lab32,
+                       (long long)n, lab64);
+    HIPCHECK(hipGetLastError());
+    return ivf_append_labelled(h, n, xdev, lab64, (uint32_t)h->ivf_ntotal, ids_dev, ids_host == nullptr, nullptr);
 }
 
 // place vectors (already on the device as (n, ld) fp32) into the lists of their nearest centroids
 static int ivf_add_device_f32(ssmi_index* h, int64_t n, const float* xdev) {
-    std::vector<int> labels;
+    int64_t* labels = nullptr;
     CHECK(assign_to_centroids(h, n, xdev, &labels));
-    return ivf_append_preassigned(h, n, xdev, labels.data(), nullptr);
+    return ivf_append_labelled(h, n, xdev, labels, (uint32_t)h->ivf_ntotal, nullptr, true, nullptr);
 }
 
 // list-sharded add: every rank sees the same vectors, assigns them all, and keeps those whose list l
@@ -773,21 +852,16 @@ int ivf_add_shard(ssmi_index* h, int64_t n, const void* x, int src_dtype, int me
     const RowStore& R = h->rows;
     const size_t el = src_dtype == SSMI_F32 ? 4 : 2;
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(1 << 16, ((size_t)1 << 30) / ((size_t)R.ld * 4)));
-    std::vector<int> labels, sel_labels, sel_src;
-    std::vector<uint32_t> sel_ids;
     for (int64_t done = 0; done < n; done += chunk) {
         const int64_t cnt = std::min(chunk, n - done);
         const float* xdev = nullptr;
+        int64_t* labels = nullptr;
         CHECK(rows_to_device_f32(h, cnt, (const char*)x + (size_t)done * R.d * el, src_dtype, mem_kind, &xdev));
         CHECK(assign_to_centroids(h, cnt, xdev, &labels));
-        sel_labels.clear(); sel_src.clear(); sel_ids.clear();
-        for (int64_t i = 0; i < cnt; ++i)
-            if (labels[i] % nshards == shard) {
-                sel_labels.push_back(labels[i]);
-                sel_src.push_back((int)i);
-                sel_ids.push_back((uint32_t)(id0 + done + i));
-            }
-        CHECK(ivf_append_preassigned(h, (int64_t)sel_labels.size(), xdev, sel_labels.data(), sel_ids.data(), sel_src.data()));
+        hipLaunchKernelGGL(mask_shard_labels_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, labels,
+                           (long long)cnt, h->nlist, shard, nshards);
+        HIPCHECK(hipGetLastError());
+        CHECK(ivf_append_labelled(h, cnt, xdev, labels, (uint32_t)(id0 + done), nullptr, false, nullptr));
     }
     return 0;
 }
@@ -1186,7 +1260,7 @@ int ssmi_index_assign(ssmi_index* h, int64_t n, const void* x, int src_dtype, in
         const int64_t cnt = std::min(chunk, n - done);
         const float* xdev = nullptr;
         CHECK(rows_to_device_f32(h, cnt, (const char*)x + (size_t)done * R.d * el, src_dtype, mem_kind, &xdev));
-        CHECK(assign_to_centroids(h, cnt, xdev, &labels));
+        CHECK(assign_to_centroids_host(h, cnt, xdev, &labels));
         std::copy(labels.begin(), labels.end(), labels_out_host + done);
     }
     return 0;
@@ -1222,7 +1296,7 @@ int ssmi_index_add_preassigned(ssmi_index* h, int64_t n, const void* x, int src_
         const int64_t cnt = std::min(chunk, n - done);
         const float* xdev = nullptr;
         CHECK(rows_to_device_f32(h, cnt, (const char*)x + (size_t)done * R.d * el, src_dtype, mem_kind, &xdev));
-        CHECK(ivf_append_preassigned(h, cnt, xdev, labels_host + done, ids32.data() + done, nullptr));
+        CHECK(ivf_append_preassigned(h, cnt, xdev, labels_host + done, ids32.data() + done));
     }
     return 0;
     });

@@ -41,7 +41,6 @@ inline const IvfState* st(const ssmi_index* h) { return reinterpret_cast<const I
 int rows_to_device_f32(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind, const float** out);
 int install_centroids(ssmi_index* h, const float* c, int mem_kind);
 // append vectors (on the device as (n, ld) fp32) to given lists; ids == nullptr: sequential ids from ntotal
-int ivf_append_preassigned(ssmi_index* h, int64_t n, const float* xdev, const int* labels, const uint32_t* ids_host,
-                           const int* src_idx_host = nullptr);
+int ivf_append_preassigned(ssmi_index* h, int64_t n, const float* xdev, const int* labels, const uint32_t* ids_host);
 
 }  // namespace ssmi

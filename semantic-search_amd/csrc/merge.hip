@@ -23,6 +23,27 @@ __global__ void merge_keys_kernel(const skey_t* __restrict__ partial, int P, int
                       D + (size_t)q * k, I + (size_t)q * k, id_offset, PlanOut{nullptr, nullptr, nullptr, nullptr}, min_ord);
 }
 
+// k == 1 (centroid assignment of an add or a k-means pass: 65536 queries a launch): the merge is a maximum over
+// the P keys of a query - one thread per query, no workgroup per query, no LDS
+__global__ void __launch_bounds__(256) merge_top1_kernel(const skey_t* __restrict__ partial, int nq, int P, float* __restrict__ D,
+                                                         int64_t* __restrict__ I, int64_t id_offset, unsigned min_ord) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const skey_t* p = partial + (size_t)q * P;
+    skey_t best = 0;
+    int e = 0;
+    if ((P & 1) == 0 && (reinterpret_cast<uintptr_t>(partial) & 15) == 0) {
+        const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(p);
+        for (; e < P; e += 2) {
+            const ulonglong2 v = p2[e >> 1];
+            best = kmax(best, kmax((skey_t)v.x, (skey_t)v.y));
+        }
+    }
+    for (; e < P; ++e) best = kmax(best, p[e]);
+    if (best == 0 || (unsigned)(best >> 32) < min_ord) { D[q] = SSMI_NEG_MAX; I[q] = -1; }
+    else { D[q] = key_score(best); I[q] = (int64_t)key_id(best) + id_offset; }
+}
+
 // lists given as (D, I) pairs laid out [nlists][nq][k]
 template <int R>
 __global__ void merge_lists_kernel(const float* __restrict__ Dl, long long d_stride, const int64_t* __restrict__ Il,
@@ -79,6 +100,10 @@ static int merge_waves(int P, int kp) {
 hipError_t launch_merge_keys(const skey_t* partial, int nq, int P, int k, float* D, int64_t* I, int64_t id_offset,
                              hipStream_t s, unsigned min_ord) {
     if (nq <= 0) return hipSuccess;
+    if (k == 1 && nq >= 1024) {
+        hipLaunchKernelGGL(merge_top1_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, partial, nq, P, D, I, id_offset, min_ord);
+        return hipGetLastError();
+    }
     const int r = pow2_ceil((k + 63) / 64);
     const int w = merge_waves(P, 64 * r);
     const size_t lds = (size_t)w * 64 * r * sizeof(skey_t);

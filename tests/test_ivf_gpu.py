@@ -333,3 +333,65 @@ def test_fp32_lists_shadow_follows_adds(ssa):
     assert index.last_timing()["last_grid"] < 0
     assert (I[:, 0] == np.arange(0, 4000, 100)).all() and (D[:, 0] > 0.999).all()
     index.close()
+
+
+def _file_lists(path, d, nlist):
+    """ids of every inverted list in storage order, parsed from the IwFl file (layout: csrc/persist.hip header)."""
+    import struct
+    raw = path.read_bytes()
+    at = 4 + 33 + 16 + 4 + 33 + 8 + nlist * d * 4 + 9
+    assert raw[at:at + 4] == b"ilar" and raw[at + 20:at + 24] == b"full"
+    at += 32
+    sizes = np.frombuffer(raw, dtype="<u8", count=nlist, offset=at).astype(np.int64)
+    at += nlist * 8
+    out = []
+    for s in sizes:
+        at += int(s) * d * 4
+        out.append(np.frombuffer(raw, dtype="<i8", count=int(s), offset=at).copy())
+        at += int(s) * 8
+    assert at == len(raw)
+    return out
+
+
+@pytest.mark.parametrize("n,d,nlist,steps", [(150000, 32, 3, (150000,)),        # few long lists, several blocks and chunks
+                                              (70000, 32, 40000, (70000,)),     # more lists than the LDS cursors hold
+                                              (9000, 64, 37, (1, 30, 31, 33, 1000, 7905))])  # page tails of every fill
+def test_device_bucketing_is_stable_and_complete(ssa, tmp_path, n, d, nlist, steps):
+    """K7 (csrc/ivf_bucket.hip): every added vector lands in its list exactly once, in add order, whatever the
+    split into add calls - against numpy's stable argsort of the labels."""
+    X = clustered_rows(n, d, min(nlist, 64), 71)
+    rng = np.random.Generator(np.random.Philox(72))
+    C = X[rng.choice(n, nlist, replace=False)] if nlist > 64 else clustered_rows(nlist, d, nlist, 73)
+    index = make_ivf(ssa, d, nlist)
+    index.set_centroids(C)
+    index.make_direct_map()
+    at = 0
+    for s in steps:
+        index.add(X[at:at + s])
+        at += s
+    assert at == n and index.ntotal == n
+    labels = index.assignments()
+    if len(steps) == 1:
+        np.testing.assert_array_equal(labels, index.assign(X))
+    else:  # single vectors are assigned on fp32 centroids, batches on their fp16 copies
+        assert ivf_flat.assignment_is_valid(X, C, labels, rtol=2e-3)
+    np.testing.assert_array_equal(index.list_sizes(), np.bincount(labels, minlength=nlist))
+    ssa.write_index(index, tmp_path / "ivf.faiss")
+    order = np.argsort(labels, kind="stable")
+    bounds = np.concatenate([[0], np.cumsum(np.bincount(labels, minlength=nlist))])
+    for l, ids in enumerate(_file_lists(tmp_path / "ivf.faiss", d, nlist)):
+        np.testing.assert_array_equal(ids, order[bounds[l]:bounds[l + 1]], err_msg=f"list {l}")
+    pick = rng.choice(n, 50, replace=False)
+    np.testing.assert_array_equal(index.reconstruct_batch(pick), X[pick])   # the direct map followed every add
+    # explicit ids through add_preassigned take the same path with host labels
+    twin = make_ivf(ssa, d, nlist)
+    twin.set_centroids(C)
+    ids = (np.arange(n, dtype=np.int64) * 3 + 7)
+    twin.add_preassigned(X[: n // 2], labels[: n // 2], ids[: n // 2])
+    twin.add_preassigned(X[n // 2:], labels[n // 2:], ids[n // 2:])
+    ssa.write_index(twin, tmp_path / "twin.faiss")
+    for l, got in enumerate(_file_lists(tmp_path / "twin.faiss", d, nlist)):
+        np.testing.assert_array_equal(got, ids[order[bounds[l]:bounds[l + 1]]], err_msg=f"list {l}")
+    with pytest.raises(RuntimeError, match="out of range"):
+        twin.add_preassigned(X[:2], np.array([0, nlist], dtype=np.int32), ids[:2])
+    index.close(); twin.close()

@@ -15,7 +15,11 @@ def rows(m):
     return x / x.norm(dim=1, keepdim=True)
 ivf = ssa.IndexIVFFlat(ssa.IndexFlatIP(d, storage="f16"), d, nlist, ssa.METRIC_INNER_PRODUCT, storage="f16")
 flat = ssa.IndexFlatIP(d, storage="f16") if os.environ.get("WITH_FLAT") else None
-ivf.train(rows(min(n, 256 * nlist)))
+xt = rows(min(n, 256 * nlist))
+torch.cuda.synchronize(); t0 = time.perf_counter()
+ivf.train(xt)
+print("train %d rows: %.3f s" % (xt.shape[0], time.perf_counter() - t0), flush=True)
+del xt
 ts = []
 for s in range(0, n, 65536):
     x = rows(min(65536, n - s))
