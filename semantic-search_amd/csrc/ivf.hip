@@ -628,7 +628,7 @@ int ivf_train(ssmi_index* h, int64_t n, const float* x, int mem_kind) {
     CHECK(install_centroids(h, C0, SSMI_DEVICE));
     h->trained = false;
 
-    // per iteration: K5 labels -> K7 buckets (perm, off) -> K6 means, all on the device; the host only sees the
+    // per iteration: K5 labels -> K7b buckets (perm, off) -> K6 means, all on the device; the host only sees the
     // nlist list sizes (for the empty-cluster fix)
     int *d_perm = nullptr, *d_off = nullptr;
     int64_t* d_labels = nullptr;
@@ -723,7 +723,7 @@ static int ensure_slots(ssmi_index* h, long long npages) {
 }
 
 // append vectors (on the device as (n, ld) fp32) to the lists their labels name (int64 on the device; kBucketSkip
-// leaves a vector out).  Vector i takes the id ids_dev[i], or id0 + i.  K7 on the device ranks every vector inside
+// leaves a vector out).  Vector i takes the id ids_dev[i], or id0 + i.  K7b on the device ranks every vector inside
 // its list; the host sees the nlist per-list counts, gives every list its pages (consecutive numbers per list and
 // add) and hands back three ints per list from which a kernel derives every vector's slot.
 // The host-side list state (sizes, page tables, direct map) is committed only when every step that can fail
@@ -734,7 +734,7 @@ static int ivf_append_labelled(ssmi_index* h, int64_t n, const float* xdev, cons
     if (n == 0) return 0;
     IvfState* S = st(h);
     const int nlist = h->nlist;
-    // workspace 15: [K7 tables][off nlist+1][fill 3*nlist]; workspace 9: [rank n][slot n]
+    // workspace 15: [K7b tables][off nlist+1][fill 3*nlist]; workspace 9: [rank n][slot n]
     const size_t bucket_bytes = (ivf_bucket_ws_bytes(n, nlist) + 255) & ~(size_t)255;
     CHECK(ensure_ws(h, 15, bucket_bytes + ((size_t)nlist * 4 + 1) * 4));
     CHECK(ensure_ws(h, 9, (size_t)n * 8));

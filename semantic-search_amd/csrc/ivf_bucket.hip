@@ -1,4 +1,4 @@
-// ivf_bucket.hip - K7: bucketing of vectors by inverted list on the device.
+// ivf_bucket.hip - K7b: bucketing of vectors by inverted list on the device.
 //
 //   labels (list of every vector)  ->  histogram  ->  exclusive prefix sum (list offsets)  ->  stable scatter
 //

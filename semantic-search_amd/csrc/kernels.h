@@ -65,7 +65,7 @@ hipError_t launch_fill_empty(float* D, int64_t* I, long long n, hipStream_t s);
 // pad queries (nq,d) -> (nq,ld) fp32 (zero tail)
 hipError_t launch_pad_queries(const float* q, int nq, int d, int ld, float* out, hipStream_t s);
 
-// K7 (ivf_bucket.hip): vectors bucketed by inverted list - histogram, exclusive prefix sum (off), stable scatter
+// K7b (ivf_bucket.hip): vectors bucketed by inverted list - histogram, exclusive prefix sum (off), stable scatter
 // (perm: members of every list in input order; rank: position of every vector among its list's vectors of this batch)
 static constexpr int64_t kBucketSkip = -2;  // label of a vector that is left out (list owned by another rank)
 size_t ivf_bucket_ws_bytes(long long n, int nlist, int* chunk_out = nullptr);

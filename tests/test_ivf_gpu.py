@@ -357,7 +357,7 @@ def _file_lists(path, d, nlist):
                                               (70000, 32, 40000, (70000,)),     # more lists than the LDS cursors hold
                                               (9000, 64, 37, (1, 30, 31, 33, 1000, 7905))])  # page tails of every fill
 def test_device_bucketing_is_stable_and_complete(ssa, tmp_path, n, d, nlist, steps):
-    """K7 (csrc/ivf_bucket.hip): every added vector lands in its list exactly once, in add order, whatever the
+    """K7b (csrc/ivf_bucket.hip): every added vector lands in its list exactly once, in add order, whatever the
     split into add calls - against numpy's stable argsort of the labels."""
     X = clustered_rows(n, d, min(nlist, 64), 71)
     rng = np.random.Generator(np.random.Philox(72))
