@@ -1108,6 +1108,18 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
             {   // is the spread of the finish times inside the blocks or between them?
                 const int nwb = qthreads / 64;
                 double within = 0, bmin = 1e30, bmax = 0;
+                double xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // mean finish time of the blocks of every XCD (block b runs on XCD b % 8)
+                for (int b = 0; b < gx; ++b)
+                    for (int w = 0; w < nwb; ++w) xcd[b % 8] += (double)(d[((size_t)b * nwb + w) * 4 + 2] - t0) * 0.01 / (nwb * (gx / 8.0));
+                fprintf(stderr, "[ivf stamp] rows-done mean per XCD: %.1f %.1f %.1f %.1f %.1f %.1f %.1f %.1f us\n", xcd[0], xcd[1], xcd[2],
+                        xcd[3], xcd[4], xcd[5], xcd[6], xcd[7]);
+                if (getenv("SSMI_IVF_STAMP_BLOCKS")) {  // mean finish time of every block, 32 a line
+                    for (int b = 0; b < gx; ++b) {
+                        double m = 0;
+                        for (int w = 0; w < nwb; ++w) m += (double)(d[((size_t)b * nwb + w) * 4 + 2] - t0) * 0.01 / nwb;
+                        fprintf(stderr, "%.0f%c", m, (b % 32 == 31) ? '\n' : ' ');
+                    }
+                }
                 for (int b = 0; b < gx; ++b) {
                     double lo = 1e30, hi = 0, sum2 = 0;
                     for (int w = 0; w < nwb; ++w) {
