@@ -467,7 +467,11 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
         const int64_t cap = std::max<int64_t>(p.bt, (int64_t)(((size_t)256 << 20) / per_q) / p.bt * p.bt);
         if (nb > cap) nb = cap;
         p.grid_y = (int)((nb + p.bt - 1) / p.bt);
+#ifdef SSMI_SCAN_STAMP
+        CHECK(ensure_ws(h, 2, (size_t)nb * per_q + (size_t)p.grid_x * 16 * 8));
+#else
         CHECK(ensure_ws(h, 2, (size_t)nb * per_q));
+#endif
         skey_t* partial = (skey_t*)h->ws[2];
         const float* qb = qdev + (size_t)done * R.ld;
         // the scan merges its own per-block lists when a ticket counter per query tile is at hand
@@ -482,10 +486,28 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
             plan->done = true;
         }
         const bool rec = record && first && h->timing_on;
+#ifdef SSMI_SCAN_STAMP
+        if (getenv("SSMI_SCAN_STAMP_SWAP")) p.tail.id_offset |= 1ll << 62;
+#endif
         if (rec) HIPCHECK(hipEventRecord(ev[0], s));
         if (R.dtype == SSMI_F32) HIPCHECK(launch_flat_scan_f32(R.view(), qb, (int)nb, k, partial, p, s));
         else HIPCHECK(launch_flat_scan_f16(R.view(), qb, (int)nb, k, partial, p, s));
         if (rec) HIPCHECK(hipEventRecord(ev[1], s));
+#ifdef SSMI_SCAN_STAMP
+        if (getenv("SSMI_SCAN_STAMP_PRINT") && record) {  // finish time of the rows per XCD (block b runs on XCD b % 8)
+            HIPCHECK(hipStreamSynchronize(s));
+            const int nwv = p.threads / 64;
+            std::vector<unsigned long long> st((size_t)p.grid_x * nwv);
+            HIPCHECK(hipMemcpy(st.data(), (char*)h->ws[2] + (size_t)nb * per_q, st.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (auto v : st) { t0 = std::min(t0, v); t1 = std::max(t1, v); }
+            double xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int b = 0; b < p.grid_x; ++b)
+                for (int w = 0; w < nwv; ++w) xcd[b % 8] += (double)(st[(size_t)b * nwv + w] - t0) * 0.01 / (nwv * (p.grid_x / 8.0));
+            fprintf(stderr, "[scan stamp] grid %d x %d waves; rows-done after the first wave to finish, mean per XCD: %.0f %.0f %.0f %.0f %.0f %.0f %.0f %.0f us; last wave %.0f us\n",
+                    p.grid_x, nwv, xcd[0], xcd[1], xcd[2], xcd[3], xcd[4], xcd[5], xcd[6], xcd[7], (double)(t1 - t0) * 0.01);
+        }
+#endif
         if (!tail)
             HIPCHECK(launch_merge_keys(partial, (int)nb, p.grid_x, k, Ddev + (size_t)done * k, Idev + (size_t)done * k,
                                        id_offset, s, min_ord));

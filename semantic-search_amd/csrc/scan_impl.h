@@ -92,7 +92,13 @@ __global__ void __launch_bounds__(QREG ? (R <= 4 ? 768 : 512) : 1024) flat_scan_
     const int nch = NCH > 0 ? NCH : (ld + 64 * V - 1) / (64 * V);
 
     const long long rpb = (X.nrows + gridDim.x - 1) / gridDim.x;
+#ifdef SSMI_SCAN_STAMP
+    // diagnostic: tail.id_offset bit 62 swaps the row slices of neighbouring blocks (is a slow block slow because
+    // of its XCD or because of its rows?)
+    const long long r0 = (long long)((tail.id_offset >> 62) & 1 ? (blockIdx.x ^ 1u) : blockIdx.x) * rpb;
+#else
     const long long r0 = (long long)blockIdx.x * rpb;
+#endif
     const long long r1 = (r0 + rpb < X.nrows) ? (r0 + rpb) : X.nrows;
     const long long seg_mask = (1ll << X.seg_shift) - 1;
 
@@ -194,6 +200,11 @@ __global__ void __launch_bounds__(QREG ? (R <= 4 ? 768 : 512) : 1024) flat_scan_
         }
     }
 
+#ifdef SSMI_SCAN_STAMP
+    // diagnostic build: wall clock (100 MHz) at which every wave finished its rows, behind the partial lists
+    if (lane == 0 && blockIdx.y == 0)
+        reinterpret_cast<unsigned long long*>(partial + (size_t)nq * gridDim.x * k)[(size_t)blockIdx.x * nwaves + wave] = wall_clock64();
+#endif
     // block-level merge through LDS (reuses the query area)
     __syncthreads();
     skey_t* lds_keys = reinterpret_cast<skey_t*>(smem);
