@@ -85,13 +85,15 @@ __global__ void widen_labels_kernel(const int* __restrict__ in, long long n, int
 
 // slot of every new vector from its rank among the batch's vectors of its list.  fill[l] = {first free slot in the
 // list's last page, free slots there, first of the consecutive pages this add gave the list}
-__global__ void slots_from_rank_kernel(const int64_t* __restrict__ labels, const int* __restrict__ rank, long long n,
-                                       const int* __restrict__ fill, int* __restrict__ dst_slot) {
+// (the fill entry of vector i is that of its list, or of entry[i] when the table is per batch: small batches)
+__global__ void slots_from_rank_kernel(const int64_t* __restrict__ labels, const int* __restrict__ entry,
+                                       const int* __restrict__ rank, long long n, const int* __restrict__ fill,
+                                       int* __restrict__ dst_slot) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int r = rank[i];
     if (r < 0) { dst_slot[i] = -1; return; }
-    const int* f = fill + 3 * (size_t)labels[i];
+    const int* f = fill + 3 * (size_t)(entry ? entry[i] : labels[i]);
     const int room = f[1];
     const int over = r - room;
     dst_slot[i] = over < 0 ? f[0] + r : (f[2] + (over >> kPageShift)) * kPageRows + (over & (kPageRows - 1));
@@ -535,10 +537,17 @@ int rows_to_device_f32(ssmi_index* h, int64_t n, const void* x, int src_dtype, i
     return 0;
 }
 
+// smallest batch whose coarse quantizer runs on the fp16 centroids (MFMA kernels); below it the exact fp32 scan
+static int coarse_mfma_min() {
+    const char* e = getenv("SSMI_IVF_COARSE_MFMA_MIN");
+    const int v = e ? atoi(e) : 9;
+    return v < 1 ? 1 : v;
+}
+
 // K5: nearest centroid (max inner product) of n device rows -> int64 labels on the device (default: workspace 7)
 static int assign_to_centroids(ssmi_index* h, int64_t n, const float* xdev, int64_t** labels_dev, int64_t* into = nullptr) {
     IvfState* S = st(h);
-    const RowStore& C = (n >= 9 && (S->cent16.ld % 64) == 0) ? S->cent16 : S->cent32;
+    const RowStore& C = (n >= coarse_mfma_min() && (S->cent16.ld % 64) == 0) ? S->cent16 : S->cent32;
     CHECK(ensure_ws(h, 6, (size_t)n * 4));
     if (!into) {
         CHECK(ensure_ws(h, 7, (size_t)n * 8));
@@ -734,42 +743,64 @@ static int ivf_append_labelled(ssmi_index* h, int64_t n, const float* xdev, cons
     if (n == 0) return 0;
     IvfState* S = st(h);
     const int nlist = h->nlist;
-    // workspace 15: [K7b tables][off nlist+1][fill 3*nlist]; workspace 9: [rank n][slot n]
-    const size_t bucket_bytes = (ivf_bucket_ws_bytes(n, nlist) + 255) & ~(size_t)255;
-    CHECK(ensure_ws(h, 15, bucket_bytes + ((size_t)nlist * 4 + 1) * 4));
-    CHECK(ensure_ws(h, 9, (size_t)n * 8));
-    int* d_off = (int*)((char*)h->ws[15] + bucket_bytes);
-    int* d_fill = d_off + nlist + 1;
-    int* d_rank = (int*)h->ws[9];
-    int* d_slot = d_rank + n;
-    const int* d_total = nullptr;
-    HIPCHECK(launch_ivf_bucket(labels_dev, n, nlist, h->ws[15], d_off, nullptr, d_rank, &d_total, h->stream));
-    std::vector<int> count((size_t)nlist + 1);
-    HIPCHECK(hipMemcpyAsync(count.data(), d_total, (size_t)(nlist + 1) * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    if (count[nlist]) return fail("add: a vector names a list outside [0, %d)", nlist);
-
     struct Undo { int list; int new_pages; long long old_size; };
     std::vector<Undo> undo;
-    std::vector<int> fill((size_t)nlist * 3, 0);
     const size_t dm_size0 = S->direct_map.size();
     const long long npages0 = S->npages;
     long long added = 0;
-    for (int l = 0; l < nlist; ++l) {
-        const int c = count[l];
-        if (!c) continue;
+    // list l takes c more vectors: pages for them (consecutive numbers), and the three ints from which a kernel
+    // derives the slot of the vector of rank r in this batch
+    auto take = [&](int l, int c, int* f) {
         const long long pos = S->size[l];
         const int in_page = (int)(pos & (kPageRows - 1));
         const int room = in_page ? kPageRows - in_page : 0;
         const int new_pages = c > room ? (c - room + kPageRows - 1) >> kPageShift : 0;
-        fill[(size_t)l * 3 + 0] = room ? S->pages[l].back() * kPageRows + in_page : 0;
-        fill[(size_t)l * 3 + 1] = room;
-        fill[(size_t)l * 3 + 2] = (int)S->npages;
+        f[0] = room ? S->pages[l].back() * kPageRows + in_page : 0;
+        f[1] = room;
+        f[2] = (int)S->npages;
         undo.push_back({l, new_pages, pos});
         for (int p = 0; p < new_pages; ++p) S->pages[l].push_back((int)(S->npages + p));
         S->npages += new_pages;
         S->size[l] = pos + c;
         added += c;
+    };
+    const bool small = n <= kBucketSmall;
+    int *d_rank, *d_slot, *d_fill, *d_entry = nullptr;
+    std::vector<int> fill;
+    if (small) {
+        // workspace 9: [rank n][slot n][last n][fill 3n][touched n+1 int2]
+        CHECK(ensure_ws(h, 9, (size_t)n * 4 * 8 + 8));
+        d_rank = (int*)h->ws[9];
+        d_slot = d_rank + n;
+        d_entry = d_slot + n;
+        d_fill = d_entry + n;
+        int2* d_touched = (int2*)(d_fill + 3 * n);
+        HIPCHECK(launch_ivf_bucket_small(labels_dev, (int)n, nlist, d_rank, d_entry, d_touched, h->stream));
+        std::vector<int2> touched((size_t)n + 1);
+        HIPCHECK(hipMemcpyAsync(touched.data(), d_touched, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        if (touched[(size_t)n].x) return fail("add: a vector names a list outside [0, %d)", nlist);
+        fill.assign((size_t)n * 3, 0);
+        for (int64_t i = 0; i < n; ++i)
+            if (touched[(size_t)i].x >= 0) take(touched[(size_t)i].x, touched[(size_t)i].y, &fill[(size_t)i * 3]);
+    } else {
+        // workspace 15: [K7b tables][off nlist+1][fill 3*nlist]; workspace 9: [rank n][slot n]
+        const size_t bucket_bytes = (ivf_bucket_ws_bytes(n, nlist) + 255) & ~(size_t)255;
+        CHECK(ensure_ws(h, 15, bucket_bytes + ((size_t)nlist * 4 + 1) * 4));
+        CHECK(ensure_ws(h, 9, (size_t)n * 8));
+        int* d_off = (int*)((char*)h->ws[15] + bucket_bytes);
+        d_fill = d_off + nlist + 1;
+        d_rank = (int*)h->ws[9];
+        d_slot = d_rank + n;
+        const int* d_total = nullptr;
+        HIPCHECK(launch_ivf_bucket(labels_dev, n, nlist, h->ws[15], d_off, nullptr, d_rank, &d_total, h->stream));
+        std::vector<int> count((size_t)nlist + 1);
+        HIPCHECK(hipMemcpyAsync(count.data(), d_total, (size_t)(nlist + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        if (count[nlist]) return fail("add: a vector names a list outside [0, %d)", nlist);
+        fill.assign((size_t)nlist * 3, 0);
+        for (int l = 0; l < nlist; ++l)
+            if (count[l]) take(l, count[l], &fill[(size_t)l * 3]);
     }
     auto rollback = [&]() {
         for (const Undo& u : undo) {
@@ -784,7 +815,7 @@ static int ivf_append_labelled(ssmi_index* h, int64_t n, const float* xdev, cons
         CHECK(ensure_slots(h, S->npages));
         HIPCHECK(hipMemcpyAsync(d_fill, fill.data(), fill.size() * 4, hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(slots_from_rank_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, labels_dev,
-                           (const int*)d_rank, (long long)n, (const int*)d_fill, d_slot);
+                           (const int*)d_entry, (const int*)d_rank, (long long)n, (const int*)d_fill, d_slot);
         HIPCHECK(hipGetLastError());
         const RowStore& R = h->rows;
         if (R.dtype == SSMI_F32)
@@ -993,7 +1024,7 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
         CHECK(ensure_ws(h, 7, (size_t)nb * nprobe * 8));
         CHECK(ensure_ws(h, 10, (size_t)nb * (nprobe + 1) * 8));
         CHECK(ensure_ws(h, 13, (size_t)nb * nprobe * 4));
-        const RowStore& C = (nb >= 9 && (S->cent16.ld % 64) == 0) ? S->cent16 : S->cent32;
+        const RowStore& C = (nb >= coarse_mfma_min() && (S->cent16.ld % 64) == 0) ? S->cent16 : S->cent32;
         ProbePlanRequest plan = {S->d_size, (long long*)h->ws[10], S->d_page_off, (int*)h->ws[13], false};
         CHECK(store_search(h, C, nb, qb, nprobe, (float*)h->ws[6], (int64_t*)h->ws[7], 0, s, false, list_major ? nullptr : &plan));
         if (list_major) {

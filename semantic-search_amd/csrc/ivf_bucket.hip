@@ -124,6 +124,48 @@ __global__ void __launch_bounds__(64) bucket_scatter_kernel(const int64_t* __res
     }
 }
 
+// Small batches (n <= kBucketSmall: the reference adds 16 vectors at a time, core/config.py:59): one workgroup ranks
+// the vectors against each other through LDS, no histogram over all nlist lists.  last[i] = index of the last vector
+// of i's list in the batch; that vector reports (list, count) in touched[i], every other one (-1, 0); touched[n].x is
+// the out-of-range flag.  The host then visits at most n lists instead of nlist.
+__global__ void __launch_bounds__(kBucketSmall) bucket_small_kernel(const int64_t* __restrict__ labels, int n, int nlist,
+                                                                    int* __restrict__ rank, int* __restrict__ last,
+                                                                    int2* __restrict__ touched) {
+    __shared__ int lab[kBucketSmall];
+    __shared__ int bad;
+    const int i = threadIdx.x;
+    if (i == 0) bad = 0;
+    __syncthreads();
+    const int64_t l64 = i < n ? labels[i] : kBucketSkip;
+    const bool valid = l64 >= 0 && l64 < nlist;
+    if (!valid && l64 != kBucketSkip) bad = 1;
+    lab[i] = valid ? (int)l64 : -1 - i;  // a value no other entry holds
+    __syncthreads();
+    if (i < n) {
+        int r = -1, la = i;
+        if (valid) {
+            const int l = (int)l64;
+            r = 0;
+            for (int j = 0; j < n; ++j) {  // broadcast LDS reads: every thread reads the same word
+                const bool same = lab[j] == l;
+                r += (same && j < i) ? 1 : 0;
+                la = same ? j : la;
+            }
+        }
+        rank[i] = r;
+        last[i] = la;
+        touched[i] = (valid && la == i) ? make_int2((int)l64, r + 1) : make_int2(-1, 0);
+    }
+    if (i == 0) touched[n] = make_int2(bad, 0);
+}
+
+hipError_t launch_ivf_bucket_small(const int64_t* labels, int n, int nlist, int* rank, int* last, int2* touched, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (n > kBucketSmall) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bucket_small_kernel, dim3(1), dim3(kBucketSmall), 0, s, labels, n, nlist, rank, last, touched);
+    return hipGetLastError();
+}
+
 size_t ivf_bucket_ws_bytes(long long n, int nlist, int* chunk_out) {
     // at most 256 blocks and 2^26 (block, list) counters (256 MiB), at least 1024 vectors per block
     long long nb = (1ll << 26) / nlist;

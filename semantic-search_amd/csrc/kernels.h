@@ -68,7 +68,10 @@ hipError_t launch_pad_queries(const float* q, int nq, int d, int ld, float* out,
 // K7b (ivf_bucket.hip): vectors bucketed by inverted list - histogram, exclusive prefix sum (off), stable scatter
 // (perm: members of every list in input order; rank: position of every vector among its list's vectors of this batch)
 static constexpr int64_t kBucketSkip = -2;  // label of a vector that is left out (list owned by another rank)
+static constexpr int kBucketSmall = 1024;    // batches up to this size are ranked by one workgroup (launch_ivf_bucket_small)
 size_t ivf_bucket_ws_bytes(long long n, int nlist, int* chunk_out = nullptr);
+// rank / last: n ints; touched: n+1 int2 ((list, count) at the last vector of every list, (-1, 0) elsewhere; [n].x = bad flag)
+hipError_t launch_ivf_bucket_small(const int64_t* labels, int n, int nlist, int* rank, int* last, int2* touched, hipStream_t s);
 hipError_t launch_ivf_bucket(const int64_t* labels, long long n, int nlist, void* ws, int* off, int* perm, int* rank,
                              const int** total_out, hipStream_t s);
 
