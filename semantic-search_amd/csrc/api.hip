@@ -242,6 +242,7 @@ int ssmi_index_free(ssmi_index* h) {
     if (h->has_shadow) h->shadow16.destroy();
     for (int i = 0; i < kWsSlots; ++i) if (h->ws[i]) (void)hipFree(h->ws[i]);
     if (h->tail_counters) (void)hipFree(h->tail_counters);
+    if (h->pin) (void)hipHostFree(h->pin);
     for (int i = 0; i < ssmi_index::kEvRing; ++i)
         for (int j = 0; j < 3; ++j) if (h->ev[i][j]) (void)hipEventDestroy(h->ev[i][j]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -555,22 +556,64 @@ int ssmi_index_search_min(ssmi_index* h, int64_t nq, const float* q, int q_mem_k
 
     float* Ddev = D;
     int64_t* Idev = I;
+    const size_t d_bytes = ((size_t)nq * k * 4 + 255) / 256 * 256;
+    const size_t out_bytes = d_bytes + (size_t)nq * k * 8;
     if (out_mem_kind == SSMI_HOST) {
-        const size_t d_bytes = ((size_t)nq * k * 4 + 255) / 256 * 256;
-        CHECK(ensure_ws(h, 3, d_bytes + (size_t)nq * k * 8));
+        CHECK(ensure_ws(h, 3, out_bytes));
         Ddev = (float*)h->ws[3];
         Idev = (int64_t*)((char*)h->ws[3] + d_bytes);
+    }
+    // all-host call: queries and results go through one pinned buffer [queries (nq, ld)][D][I].  (With device
+    // outputs the call returns before the copies have run, so the pinned block could not be reused safely.)
+    const size_t q_bytes = ((size_t)nq * h->rows.ld * 4 + 255) / 256 * 256;
+    unsigned char* pin = nullptr;
+    if (q_mem_kind == SSMI_HOST && out_mem_kind == SSMI_HOST && q_bytes + out_bytes <= ssmi_index::kPinMax) {
+        if (h->pin_bytes < q_bytes + out_bytes) {
+            size_t want = std::max<size_t>(64 << 10, h->pin_bytes);
+            while (want < q_bytes + out_bytes) want *= 2;
+            void* p = nullptr;
+            if (hipHostMalloc(&p, want, hipHostMallocDefault) == hipSuccess) {
+                if (h->pin) (void)hipHostFree(h->pin);
+                h->pin = p;
+                h->pin_bytes = want;
+            } else {
+                (void)hipGetLastError();  // no pinned memory: the pageable copies below still work
+            }
+        }
+        if (h->pin_bytes >= q_bytes + out_bytes) pin = (unsigned char*)h->pin;
     }
     const int64_t ntotal = h->kind == SSMI_KIND_FLAT ? h->rows.nrows : h->ivf_ntotal;
     if (ntotal == 0) {
         HIPCHECK(launch_fill_empty(Ddev, Idev, nq * k, s));
     } else {
         const float* qdev = nullptr;
-        CHECK(stage_queries(h, nq, q, q_mem_kind, s, &qdev));
+        if (pin) {
+            const RowStore& R = h->rows;
+            float* qpin = (float*)pin;
+            if (R.ld == R.d) {
+                memcpy(qpin, q, (size_t)nq * R.d * 4);
+            } else {
+                for (int64_t i = 0; i < nq; ++i) {
+                    memcpy(qpin + (size_t)i * R.ld, q + (size_t)i * R.d, (size_t)R.d * 4);
+                    memset(qpin + (size_t)i * R.ld + R.d, 0, (size_t)(R.ld - R.d) * 4);
+                }
+            }
+            CHECK(ensure_ws(h, 1, (size_t)nq * R.ld * 4));
+            HIPCHECK(hipMemcpyAsync(h->ws[1], qpin, (size_t)nq * R.ld * 4, hipMemcpyHostToDevice, s));
+            qdev = (const float*)h->ws[1];
+        } else {
+            CHECK(stage_queries(h, nq, q, q_mem_kind, s, &qdev));
+        }
         if (h->kind == SSMI_KIND_FLAT) CHECK(store_search(h, h->rows, nq, qdev, k, Ddev, Idev, id_offset, s, true, nullptr, min_ord));
         else CHECK(ivf_search(h, nq, qdev, k, Ddev, Idev, id_offset, s, min_ord));
     }
-    if (out_mem_kind == SSMI_HOST) {
+    if (pin) {  // (D, I) sit back to back in workspace 3: one copy, then out of the pinned block
+        unsigned char* opin = pin + q_bytes;
+        HIPCHECK(hipMemcpyAsync(opin, Ddev, out_bytes, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        memcpy(D, opin, (size_t)nq * k * 4);
+        memcpy(I, opin + d_bytes, (size_t)nq * k * 8);
+    } else if (out_mem_kind == SSMI_HOST) {
         HIPCHECK(hipMemcpyAsync(D, Ddev, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
         HIPCHECK(hipMemcpyAsync(I, Idev, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
         HIPCHECK(hipStreamSynchronize(s));

@@ -69,6 +69,11 @@ struct ssmi_index {
     // ticket counters of the merge tails (tail_merge.h): zero between launches, one per query (tile)
     static const int kTailCounters = 4096;
     unsigned* tail_counters = nullptr;
+    // pinned host staging of an all-host search (numpy queries in, numpy results out: the reference's call shape):
+    // copies from and to pageable memory cost ~20 us each, pinned ones ~5 us; grow-only, up to kPinMax bytes
+    void* pin = nullptr;
+    size_t pin_bytes = 0;
+    static const size_t kPinMax = (size_t)4 << 20;
 
     // ---- IVF state (kind == SSMI_KIND_IVFFLAT) ----
     int nlist = 0, nprobe = 1;
