@@ -26,6 +26,7 @@ hipError_t launch_flat_scan_f16(const RowView& X, const float* Q, int nq, int k,
 // K2 planning + launch (fp16 storage, ld % 64 == 0)
 struct MfmaPlan {
     int nqt, nslices, grid;
+    int gtop_m;   // scores every slice publishes per query for the cross-slice threshold bound (0: none)
     bool narrow;  // <= 128 queries: the HBM-bound 128-query-tile stream (mfma_n128.hip)
     long long rows_per_slice;
     size_t qh_bytes, cand_bytes, lds;

@@ -29,20 +29,24 @@
 // its own list then holds fewer than k keys, which K3 takes (key 0 = empty).
 #include "mfma_common.h"
 #include <cstdlib>
+#include <algorithm>
 
 namespace ssmi {
 
 __global__ void cvt_queries_f16_kernel(const float* __restrict__ q, int nq, int ld, _Float16* __restrict__ out,
-                                       unsigned* __restrict__ gthr) {
+                                       unsigned* __restrict__ gthr, unsigned* __restrict__ gtop, int gtop_words) {
     const int i = blockIdx.x;  // padded row
     if (gthr && threadIdx.x == 0) gthr[i] = 0;
+    if (gtop)
+        for (int e = threadIdx.x; e < gtop_words; e += blockDim.x) gtop[(size_t)i * gtop_words + e] = 0;
     for (int e = threadIdx.x; e < ld; e += blockDim.x)
         out[(size_t)i * ld + e] = (i < nq) ? (_Float16)q[(size_t)i * ld + e] : (_Float16)0.f;
 }
 
 // (nq, ld) fp32 -> (rows_out, ld) fp16, zero rows beyond nq
 hipError_t launch_cvt_queries_f16(const float* q, int nq, int rows_out, int ld, void* out, hipStream_t s) {
-    hipLaunchKernelGGL(cvt_queries_f16_kernel, dim3(rows_out), dim3(256), 0, s, q, nq, ld, (_Float16*)out, (unsigned*)nullptr);
+    hipLaunchKernelGGL(cvt_queries_f16_kernel, dim3(rows_out), dim3(256), 0, s, q, nq, ld, (_Float16*)out, (unsigned*)nullptr,
+                       (unsigned*)nullptr, 0);
     return hipGetLastError();
 }
 
@@ -56,7 +60,14 @@ bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_c
     p->rows_per_slice = (row_tiles + ns - 1) / ns * TM;
     p->nslices = (int)((nrows + p->rows_per_slice - 1) / p->rows_per_slice);
     p->grid = p->nqt * p->nslices;
-    p->qh_bytes = (size_t)p->nqt * TN * ld * 2 + (size_t)p->nqt * TN * sizeof(unsigned);  // fp16 queries + shared thresholds
+    // scores every slice publishes per query (gtop): enough of them that the k-th largest exists and is tight -
+    // about max(64, 1.25 k) entries per query over the slices, at most 8 per slice
+    int m = (int)((std::max<long long>(64, (long long)k * 5 / 4) + p->nslices - 1) / p->nslices);
+    m = std::max(1, std::min(std::min(m, 8), k));
+    p->gtop_m = (p->nslices > 1 && (long long)p->nslices * m >= k) ? m : 0;
+    // fp16 queries + shared thresholds + published tops
+    p->qh_bytes = (size_t)p->nqt * TN * ld * 2 + (size_t)p->nqt * TN * sizeof(unsigned) +
+                  (size_t)p->nqt * TN * p->nslices * p->gtop_m * sizeof(unsigned);
     p->cand_bytes = (size_t)p->grid * TN * CAND_CAP * sizeof(skey_t);
     const char* env_n = getenv("SSMI_MFMA_NARROW");
     p->narrow = nq <= N128_TN && !(env_n && env_n[0] == '0');
@@ -72,13 +83,20 @@ hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, con
     unsigned* gthr = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(qh) + (size_t)p.nqt * TN * X.ld * 2);
     const char* env_t = getenv("SSMI_MFMA_SHARE_THR");
     const bool share_thr = !(env_t && env_t[0] == '0');
-    hipLaunchKernelGGL(cvt_queries_f16_kernel, dim3(p.nqt * TN), dim3(256), 0, s, Q, nq, X.ld, (_Float16*)qh, gthr);
+    const char* env_g = getenv("SSMI_MFMA_SHARE_TOPS");
+    // (a batch of a few queries on the register-ring kernel gains nothing and pays for the ring drains of the exchange)
+    const bool share_tops = share_thr && p.gtop_m > 0 && k > 1 && !(p.narrow && nq < 32 && k <= 16) && !(env_g && env_g[0] == '0');
+    unsigned* gtop = gthr + (size_t)p.nqt * TN;
+    hipLaunchKernelGGL(cvt_queries_f16_kernel, dim3(p.nqt * TN), dim3(256), 0, s, Q, nq, X.ld, (_Float16*)qh, gthr,
+                       share_tops ? gtop : (unsigned*)nullptr, p.nslices * p.gtop_m);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     MfmaParams P;
     P.X = X; P.Qh = (const _Float16*)qh; P.nq = nq; P.k = k; P.nqt = p.nqt; P.nslices = p.nslices;
     P.rows_per_slice = p.rows_per_slice; P.partial = partial; P.cand = (skey_t*)cand;
     P.gthr = (share_thr && p.nslices > 1) ? gthr : nullptr;
+    P.gtop = share_tops ? gtop : nullptr;
+    P.gtop_m = p.gtop_m;
     P.thr_floor = min_ord ? ord_to_f32(min_ord) : SSMI_NEG_MAX;
     int r = 1;
     while (64 * r < k) r <<= 1;

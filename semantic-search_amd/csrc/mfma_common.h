@@ -22,6 +22,11 @@ struct MfmaParams {
     float thr_floor;           // score floor of the search (SSMI_NEG_MAX = none): thresholds start and stay at or above it
     unsigned* gthr;            // [nqt*256] per query: highest k-th score any slice has reached (f32_to_ord bits,
                                // 0 = none), zeroed by the query conversion; 256-query kernel only
+    // [nqt*256][nslices][gtop_m] the best gtop_m scores of every slice's list (f32_to_ord bits, 0 = none), zeroed
+    // by the query conversion: every entry is the score of a distinct database row, so the k-th largest entry of a
+    // query is a lower bound of its final k-th score - far tighter than any single slice's own k-th score
+    unsigned* gtop;
+    int gtop_m;
 #ifdef SSMI_STAMP
     unsigned long long* dbg;   // diagnostic build only: per-wave cycle sums
 #endif
@@ -75,6 +80,98 @@ struct QSlabDma {
 // LDS words behind the four operand slabs: thr[256] (float), cnt[256], kept[256], flag
 static constexpr int EPI_LDS_BYTES = 3 * 256 * 4 + 16;
 
+// ---- published tops (MfmaParams::gtop) ----
+// The wave that has just folded (q, slice) publishes the list's best gtop_m scores (lanes 0.. of its first register)
+// with device-scope stores; any wave may later read all of a query's entries with device-scope loads.  A stale or
+// still empty entry only weakens the bound, it never invalidates it.
+__device__ __forceinline__ void publish_tops(unsigned* gtop_qs /*entry of (q, slice)*/, int m, skey_t v0) {
+    const int lane = lane_id();
+    if (gtop_qs && lane < m) __hip_atomic_store(gtop_qs + lane, (unsigned)(v0 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 64*RV unsigned values spread over the lanes (element e in register e/64 of lane e%64), sorted largest first by
+// the bitonic network of topk.h on 32-bit values (half the instructions of the 64-bit key sort)
+template <int RV>
+struct WaveSort32 {
+    unsigned v[RV];
+    template <int STRIDE>
+    __device__ __forceinline__ void lane_stage(int size_bit) {
+        const int lane = lane_id();
+        const bool lower = (lane & STRIDE) == 0;
+#pragma unroll
+        for (int r = 0; r < RV; ++r) {
+            const bool desc = ((r * 64 + lane) & size_bit) == 0;
+            const unsigned p = (unsigned)xor_lane<STRIDE>((int)v[r]);
+            v[r] = (desc == lower) ? max(v[r], p) : min(v[r], p);
+        }
+    }
+    __device__ __forceinline__ void reg_stage(int rs, int size_bit) {
+#pragma unroll
+        for (int r = 0; r < RV; ++r)
+            if ((r & rs) == 0 && r + rs < RV) {
+                const bool desc = ((r * 64) & size_bit) == 0;
+                const unsigned hi = max(v[r], v[r + rs]), lo = min(v[r], v[r + rs]);
+                v[r] = desc ? hi : lo;
+                v[r + rs] = desc ? lo : hi;
+            }
+    }
+    template <int START>
+    __device__ __forceinline__ void lane_stages(int size_bit) {
+        if constexpr (START >= 32) lane_stage<32>(size_bit);
+        if constexpr (START >= 16) lane_stage<16>(size_bit);
+        if constexpr (START >= 8) lane_stage<8>(size_bit);
+        if constexpr (START >= 4) lane_stage<4>(size_bit);
+        if constexpr (START >= 2) lane_stage<2>(size_bit);
+        lane_stage<1>(size_bit);
+    }
+    __device__ __forceinline__ void sort_desc() {
+        lane_stages<1>(2);
+        lane_stages<2>(4);
+        lane_stages<4>(8);
+        lane_stages<8>(16);
+        lane_stages<16>(32);
+        lane_stages<32>(RV == 1 ? 0 : 64);
+#pragma unroll
+        for (int size = 128; size <= 64 * RV; size <<= 1) {
+            const int sb = (size == 64 * RV) ? 0 : size;
+#pragma unroll
+            for (int rs = size >> 7; rs >= 1; rs >>= 1) reg_stage(rs, sb);
+            lane_stages<32>(sb);
+        }
+    }
+    __device__ __forceinline__ unsigned kth(int k) const {  // 1-based, wave-uniform
+        const int e = k - 1;
+        unsigned sel = 0;
+#pragma unroll
+        for (int r = 0; r < RV; ++r) sel = ((e >> 6) == r) ? v[r] : sel;
+        return (unsigned)__builtin_amdgcn_readlane((int)sel, e & 63);
+    }
+};
+template <int RV>
+__device__ __forceinline__ unsigned tops_bound_r(const unsigned* g, int V, int k) {
+    const int lane = lane_id();
+    WaveSort32<RV> t;
+#pragma unroll
+    for (int r = 0; r < RV; ++r) {
+        const int e = r * 64 + lane;
+        t.v[r] = e < V ? __hip_atomic_load(g + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    }
+    t.sort_desc();
+    return t.kth(k);
+}
+// k-th largest of the first V published scores of query q (f32_to_ord bits; 0: fewer than k published).  Any
+// subset of the entries bounds as well, so V is only as large as k needs: 64 entries up to k = 48, 128 up to
+// k = 100, 256 beyond.  Wave-uniform, all lanes call.
+__device__ __forceinline__ unsigned tops_bound(const MfmaParams& P, int q) {
+    const int cap = P.k <= 48 ? 64 : (P.k <= 100 ? 128 : 256);
+    int V = P.nslices * P.gtop_m;
+    if (V > cap) V = cap;
+    if (P.k > V) return 0u;
+    const unsigned* g = P.gtop + (size_t)q * P.nslices * P.gtop_m;
+    if (V <= 64) return tops_bound_r<1>(g, V, P.k);
+    if (V <= 128) return tops_bound_r<2>(g, V, P.k);
+    return tops_bound_r<4>(g, V, P.k);
+}
+
 // Fold the candidate buffer of one query into its sorted k-list and raise its threshold.
 // One wave per query.  Candidates arrive unsorted: they are sorted in registers (bitonic
 // network, 64 or 256 at a time) and merged with the kept list by one bitonic merge - far cheaper
@@ -82,7 +179,8 @@ static constexpr int EPI_LDS_BYTES = 3 * 256 * 4 + 16;
 // `kept`: the query's k-list in global memory (k keys), valid once kept_l[ql] is set.
 template <int R>
 __device__ __forceinline__ void compact_list(int ql, skey_t* kept, int k, skey_t* cand_q, float* thr_l, unsigned* cnt_l,
-                                             unsigned* kept_l, float thr_floor = SSMI_NEG_MAX) {
+                                             unsigned* kept_l, float thr_floor = SSMI_NEG_MAX, unsigned* gtop_qs = nullptr,
+                                             int gtop_m = 0) {
     const int lane = lane_id();
     const int n = (int)min(cnt_l[ql], (unsigned)CAND_CAP);
     if (n == 0 && kept_l[ql]) return;  // nothing new: list and threshold stand
@@ -108,6 +206,7 @@ __device__ __forceinline__ void compact_list(int ql, skey_t* kept, int k, skey_t
     }
     const skey_t thrk = t.kth(k);
     t.store(kept, k);
+    publish_tops(gtop_qs, gtop_m, t.v[0]);
     if (lane == 0) {
         kept_l[ql] = 1;
         cnt_l[ql] = 0;
@@ -118,7 +217,8 @@ __device__ __forceinline__ void compact_list(int ql, skey_t* kept, int k, skey_t
 template <int R>
 __device__ __forceinline__ void compact_query(int ql, int q, const MfmaParams& P, int slice, skey_t* cand_q,
                                               float* thr_l, unsigned* cnt_l, unsigned* kept_l) {
-    compact_list<R>(ql, P.partial + ((size_t)q * P.nslices + slice) * P.k, P.k, cand_q, thr_l, cnt_l, kept_l, P.thr_floor);
+    compact_list<R>(ql, P.partial + ((size_t)q * P.nslices + slice) * P.k, P.k, cand_q, thr_l, cnt_l, kept_l, P.thr_floor,
+                    P.gtop ? P.gtop + ((size_t)q * P.nslices + slice) * P.gtop_m : nullptr, P.gtop_m);
 }
 
 // LDS atomic add / store issued as opaque instructions: after an LDS-DMA (global_load_lds) the
@@ -161,7 +261,8 @@ __device__ __forceinline__ FoldOperands<R> fold_load(int ql, const skey_t* kept,
 }
 template <int R>
 __device__ __forceinline__ void fold_one(int ql, const FoldOperands<R>& o, skey_t* kept, int k, const skey_t* cand_q,
-                                         float* thr_l, unsigned* cnt_l, unsigned* kept_l, float thr_floor) {
+                                         float* thr_l, unsigned* cnt_l, unsigned* kept_l, float thr_floor,
+                                         unsigned* gtop_qs, int gtop_m) {
     const int lane = lane_id();
     if (o.n == 0 && o.has) return;  // nothing new: list and threshold stand
     WaveTopK<R> t;
@@ -186,6 +287,7 @@ __device__ __forceinline__ void fold_one(int ql, const FoldOperands<R>& o, skey_
     }
     const skey_t thrk = t.kth(k);
     t.store(kept, k);
+    publish_tops(gtop_qs, gtop_m, t.v[0]);
     if (lane == 0) {
         lds_store(&kept_l[ql], 1u);
         lds_store(&cnt_l[ql], 0u);
@@ -205,7 +307,8 @@ __device__ __forceinline__ void fold_queries(int wave, int q0, const MfmaParams&
         const int qn = ql + 8;
         FoldOperands<R> nxt = cur;
         if (qn < nql) nxt = fold_load<R>(qn, list_of(qn), P.k, cand + (size_t)qn * CAND_CAP, cnt_l, kept_l);
-        fold_one<R>(ql, cur, list_of(ql), P.k, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l, P.thr_floor);
+        fold_one<R>(ql, cur, list_of(ql), P.k, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l, P.thr_floor,
+                    P.gtop ? P.gtop + ((size_t)(q0 + ql) * P.nslices + slice) * P.gtop_m : nullptr, P.gtop_m);
         cur = nxt;
     }
 }

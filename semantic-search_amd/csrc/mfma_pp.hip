@@ -145,6 +145,29 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
 #define STAMP(i)
 #endif
     unsigned tiles_done = 0;
+    // Cross-slice bound in two cheap steps after a fold (tops_bound is a memory round trip and a 64-key sort per query,
+    // too much for every slice to do for all 256 queries): one row tile after the fold, when every slice of the
+    // query tile has published its tops, this slice computes the bound of ITS share of the queries (ql = slice mod
+    // nslices) and pushes it into gthr; another row tile later every wave pulls gthr for its queries.
+    // scheduled folds after row tiles 1, 4, 16, 64, ...; with the cross-slice bound (which matures much faster than a
+    // slice's own k-th score) after 1, 16, 256, ... only
+    const unsigned fold_mask = P.gtop ? 0x11111111u : 0x55555555u;
+    int xstate = 0;  // 1: push bounds at the next tile end, 2: pull thresholds at the next tile end
+    auto push_bounds = [&]() {
+        for (int ql = slice + wave * P.nslices; ql < 256 && q0 + ql < P.nq; ql += 8 * P.nslices) {
+            const unsigned b = tops_bound(P, q0 + ql);
+            if (b && lane == 0) atomicMax(&P.gthr[q0 + ql], b);
+        }
+    };
+    auto pull_thr = [&]() {
+        if (lane < 32) {
+            const int ql = wave + 8 * lane;
+            if (q0 + ql < P.nq) {
+                const unsigned seen = __hip_atomic_load(&P.gthr[q0 + ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen && ord_to_f32(seen) > thr_l[ql]) lds_store(reinterpret_cast<unsigned*>(&thr_l[ql]), __float_as_uint(ord_to_f32(seen)));
+            }
+        }
+    };
     float best_s[4];
     uint32_t best_r[4];
 #pragma unroll
@@ -267,7 +290,12 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
 #ifdef SSMI_STAMP_NOPASS
         if (false) {
 #else
-        if (((tiles_done & (tiles_done - 1)) == 0 && (tiles_done & 0x55555555u)) || *flag_l) {
+        const bool fold_due = ((tiles_done & (tiles_done - 1)) == 0 && (tiles_done & fold_mask)) || *flag_l;
+        if (xstate && !fold_due) {  // (the K loop's barriers publish the new thresholds before the next filter)
+            if (xstate == 1) push_bounds(); else pull_thr();
+            xstate = xstate == 1 ? 2 : 0;
+        }
+        if (fold_due) {
 #endif
             fold_queries<R>(wave, q0, P, slice, cand, thr_l, cnt_l, kept_l);
             STAMP(5)
@@ -275,6 +303,9 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
             // bound of the final k-th score, so every slice may filter with the highest one reached so far (its
             // own list then holds fewer than k keys; the merge takes that).  One atomic max per query and fold,
             // the wave's 32 queries in one round trip.
+            // The tighter bound from the slices' published tops follows one and two row tiles later (push_bounds,
+            // pull_thr above).
+            xstate = P.gtop ? 1 : 0;
             if (P.gthr && lane < 32) {
                 const int ql = wave + 8 * lane;
                 if (q0 + ql < P.nq) {

@@ -124,6 +124,28 @@ __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     unsigned tiles_done = 0;
+    // cross-slice bound from the slices' published tops, as in mfma_pp.hip: one row tile after a fold this slice
+    // computes the bound of its share of the queries and pushes it into gthr, another tile later every wave pulls
+    // scheduled folds after row tiles 1, 4, 16, 64, ...; with the cross-slice bound (which matures much faster than a
+    // slice's own k-th score) after 1, 16, 256, ... only
+    const unsigned fold_mask = P.gtop ? 0x11111111u : 0x55555555u;
+    int xstate = 0;
+    auto push_bounds = [&]() {
+        for (int ql = slice + wave * P.nslices; ql < P.nq; ql += 8 * P.nslices) {
+            const unsigned b = tops_bound(P, ql);
+            if (b && lane == 0) atomicMax(&P.gthr[ql], b);
+        }
+    };
+    auto pull_thr = [&]() {
+        if (lane < 16) {
+            const int ql = wave + 8 * lane;
+            if (ql < P.nq) {
+                const unsigned seen = __hip_atomic_load(&P.gthr[ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen && ord_to_f32(seen) > thr_l[ql]) thr_l[ql] = ord_to_f32(seen);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
     int g = 0;
     for (int t = 0; t < ntiles; ++t) {
         const long long row0 = r_begin + (long long)t * TM;
@@ -180,7 +202,12 @@ __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave's counters and flag are in LDS
         ++tiles_done;
-        if (((tiles_done & (tiles_done - 1)) == 0 && (tiles_done & 0x55555555u)) || *flag_l) {
+        const bool fold_due = ((tiles_done & (tiles_done - 1)) == 0 && (tiles_done & fold_mask)) || *flag_l;
+        if (xstate && !fold_due) {  // (the per-step barriers publish the new thresholds before the next filter)
+            if (xstate == 1) push_bounds(); else pull_thr();
+            xstate = xstate == 1 ? 2 : 0;
+        }
+        if (fold_due) {
             __syncthreads();  // drains the candidate stores (and the row stream, once per compaction)
             for (int ql = wave; ql < N128_TN; ql += 8)
                 if (ql < P.nq) compact_query<R>(ql, ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
@@ -188,6 +215,7 @@ __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
             // stays weak to the end): the k-th score of ANY slice bounds the final k-th score from below, so every
             // slice filters with the highest one reached anywhere.  Same exchange as the 256-query kernel: one
             // atomic max per query and fold, the wave's 16 queries in one round trip.
+            xstate = P.gtop ? 1 : 0;
             if (P.gthr && lane < 16) {
                 const int ql = wave + 8 * lane;
                 if (ql < P.nq) {

@@ -102,7 +102,38 @@ def test_wide_kernel_many_row_tiles(ssa, monkeypatch, n, d, nq, k, seg_shift):
     D2, I2 = index2.search(Q, k)
     ok, msg, _ = flat_ip.check_against(D2, I2, Dr, Ir, Xh, Qh, rtol=1e-5, tie_rtol=1e-5)
     assert ok, msg
+    # ... and with the gthr exchange only, without the bound from the slices' published tops
+    monkeypatch.setenv("SSMI_MFMA_SHARE_THR", "1")
+    monkeypatch.setenv("SSMI_MFMA_SHARE_TOPS", "0")
+    D3, I3 = index.search(Q, k)
+    ok, msg, _ = flat_ip.check_against(D3, I3, Dr, Ir, Xh, Qh, rtol=1e-5, tie_rtol=1e-5)
+    assert ok, msg
     index.close(); index2.close()
+
+
+@pytest.mark.parametrize("nq,k", [(300, 10), (300, 100), (64, 10), (128, 100), (1100, 50)])
+def test_cross_slice_bound_keeps_ties_and_every_winner(ssa, nq, k):
+    """The slices publish the best scores of their lists and filter with the k-th largest published score
+    (mfma_common.h: tops_bound).  Copies of one row spread over all slices tie exactly AT that bound: the result
+    must still be the k lowest ids among them, and a query whose winners all sit in one slice must lose none."""
+    n, d = 150000, 512
+    X = unit_rows(n, d, 91)
+    Q = unit_rows(nq, d, 92)
+    copies = np.arange(7, n, n // 173)[:173]          # 173 copies of Q[0], a few per slice
+    X[copies] = Q[0]
+    near = Q[1][None, :] + 0.05 * np.random.default_rng(3).standard_normal((k + 5, d)).astype(np.float32)
+    X[5000:5000 + k + 5] = near / np.linalg.norm(near, axis=1, keepdims=True)   # winners of Q[1]: one slice only
+    index = ssa.IndexFlatIP(d, storage="f16")
+    index.add(X)
+    Xh, Qh = r16(X), r16(Q)
+    Dr, Ir = flat_ip.search(Xh, Qh, k)
+    for _ in range(2):
+        D, I = index.search(Q, k)
+        ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xh, Qh, rtol=1e-5, tie_rtol=1e-5)
+        assert ok, msg
+        np.testing.assert_array_equal(I[0], copies[:k])
+        assert set(I[1]) <= set(range(5000, 5000 + k + 5))
+    index.close()
 
 
 @pytest.mark.parametrize("k", [10, 100])
