@@ -1029,13 +1029,14 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
         CHECK(store_search(h, C, nb, qb, nprobe, (float*)h->ws[6], (int64_t*)h->ws[7], 0, s, false, list_major ? nullptr : &plan));
         if (list_major) {
             CHECK(ensure_ws(h, 2, (size_t)nb * nprobe * k * sizeof(skey_t)));
-            CHECK(ensure_ws(h, 11, (size_t)(4 * h->nlist + 3) * 4));
+            CHECK(ensure_ws(h, 11, (size_t)(4 * h->nlist + 3) * 4 + (size_t)nb * 4));
             CHECK(ensure_ws(h, 12, (size_t)nb * nprobe * 4));
             IvfListScanArgs A;
             A.X = R.view(); A.Q = qb; A.Ic = (const int64_t*)h->ws[7]; A.nq = nb; A.nprobe = nprobe; A.nlist = h->nlist;
             A.k = k; A.page_off = S->d_page_off; A.pages = S->d_pages; A.list_size = S->d_size; A.slot_ids = S->d_slot_ids;
             A.cnt = (int*)h->ws[11]; A.cursor = A.cnt + h->nlist; A.eoff = A.cursor + h->nlist + 1; A.uoff = A.eoff + h->nlist + 1;
             A.entries = (int*)h->ws[12]; A.partial = (skey_t*)h->ws[2];
+            A.qthr = nullptr;
             if (list_mfma) {
                 // matrix-core form: up to 128 queries per list pass, queries rounded to fp16
                 A.bt = ivf_list_mfma_bt(nb, nprobe, h->nlist); A.threads = 512; A.lds = 0; A.max_units = 0;
@@ -1043,6 +1044,10 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
                 CHECK(ensure_ws(h, 4, (size_t)nb * R.ld * 2));
                 CHECK(ensure_ws(h, 5, ivf_list_mfma_cand_bytes(h->num_cu)));
                 HIPCHECK(launch_cvt_queries_f16(qb, nb, nb, R.ld, h->ws[4], s));
+                if (!getenv("SSMI_IVF_LIST_SHARE_THR") || getenv("SSMI_IVF_LIST_SHARE_THR")[0] != '0') {
+                    A.qthr = (unsigned*)(A.uoff + h->nlist + 1);  // behind the four tables of workspace 11
+                    HIPCHECK(hipMemsetAsync(A.qthr, 0, (size_t)nb * 4, s));
+                }
                 if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[0], s));
                 HIPCHECK(launch_ivf_list_scan_mfma(A, h->ws[4], h->ws[5], h->num_cu, s));
                 if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[1], s));

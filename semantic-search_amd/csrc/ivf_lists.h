@@ -21,6 +21,8 @@ struct IvfListScanArgs {
     int* uoff;                  // nlist+1
     int* entries;               // nq*nprobe (query*nprobe + probe), grouped by list
     skey_t* partial;            // [nq*nprobe][k]
+    unsigned* qthr;             // MFMA form: [nq] highest k-th score any probed list of the query has reached (f32_to_ord
+                                // bits, 0 = none), zeroed before the launch; nullptr: every (query, list) pair on its own
     int bt, threads, max_units;
     size_t lds;
 };

@@ -91,11 +91,31 @@ __global__ void __launch_bounds__(512) ivf_scan_lists_mfma_kernel(IvfListScanArg
         const int ntiles = (npages + 7) >> 3;  // a "tile" = 8 pages, one per wave
         const int total = ntiles * ns;
 
+        // A (query, list) pair starts from the best k-th score any other list of the query has reached so far
+        // (qthr): k rows of the query score at least that, so nothing below it can be in the final top-k.  Without
+        // it every pair starts empty: all 256 rows of its first tile survive, are stored and sorted.
         if (tid < N128_TN) {
-            thr_l[tid] = (tid < ne) ? SSMI_NEG_MAX : __builtin_inff();
+            float t0 = (tid < ne) ? SSMI_NEG_MAX : __builtin_inff();
+            if (tid < ne && A.qthr) {
+                const unsigned seen = __hip_atomic_load(&A.qthr[A.entries[e0 + tid] / A.nprobe], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen) t0 = ord_to_f32(seen);
+            }
+            thr_l[tid] = t0;
             cnt_l[tid] = 0;
             kept_l[tid] = 0;
         }
+        // after a fold: hand this pair's k-th score to the query's other lists and take theirs
+        auto share_thr = [&]() {
+            if (A.qthr && lane < BT / 8) {
+                const int ql = wave + 8 * lane;
+                if (ql < ne) {
+                    const float t = thr_l[ql];
+                    const unsigned mine = (t > SSMI_NEG_MAX) ? f32_to_ord(t) : 0u;
+                    const unsigned seen = atomicMax(&A.qthr[A.entries[e0 + ql] / A.nprobe], mine);
+                    if (seen > mine) thr_l[ql] = ord_to_f32(seen);
+                }
+            }
+        };
         if (tid == 0) *flag_l = 0;
         __syncthreads();
 
@@ -216,6 +236,7 @@ __global__ void __launch_bounds__(512) ivf_scan_lists_mfma_kernel(IvfListScanArg
                     for (int ql = wave; ql < ne; ql += 8)
                         compact_list<R>(ql, A.partial + (size_t)A.entries[e0 + ql] * A.k, A.k, cand + (size_t)ql * CAND_CAP,
                                         thr_l, cnt_l, kept_l);
+                    share_thr();
                     __syncthreads();
                     if (tid == 0) *flag_l = 0;
                 }
@@ -230,6 +251,7 @@ __global__ void __launch_bounds__(512) ivf_scan_lists_mfma_kernel(IvfListScanArg
         for (int ql = wave; ql < ne; ql += 8)
             compact_list<R>(ql, A.partial + (size_t)A.entries[e0 + ql] * A.k, A.k, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l,
                             kept_l);
+        share_thr();
     }
 }
 
