@@ -1,0 +1,29 @@
+"""K1 (batch 1) on fp16 or fp32 rows at one database size, environment variants flipped in one process:
+time_flat_sizes.py n d storage iters VAR=a,b [VAR2=c,d ...]"""
+import sys, os, itertools
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import semantic_search_amd as ssa
+n, d, storage, iters = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+variants = [(a.split("=")[0], a.split("=")[1].split(",")) for a in sys.argv[5:]]
+ix = ssa.IndexFlatIP(d, storage=storage); ix.add_random_unit(n, 1234)
+el = 2 if storage == "f16" else 4
+g = torch.Generator().manual_seed(1); Q = torch.randn((4, 1, d), generator=g); Q = (Q / Q.norm(dim=-1, keepdim=True)).cuda()
+ref = None
+for rnd in range(2):
+    for combo in itertools.product(*[v for _, v in variants]):
+        for (name, _), val in zip(variants, combo):
+            os.environ[name] = val
+        for it in range(3):
+            ix.search(Q[it % 4], 10)
+        torch.cuda.synchronize()
+        for it in range(iters):
+            D, I = ix.search(Q[it % 4], 10)
+        torch.cuda.synchronize()
+        ms = ix.scan_times_ms(iters)
+        if ref is None:
+            ref = (D.clone(), I.clone())
+        assert torch.equal(ref[0], D) and torch.equal(ref[1], I), "variant changes the result"
+        print("n=%d %s round %d %s: mean %.3f ms min %.3f -> %.2f TB/s (%.3f of 8)" % (
+            n, storage, rnd, " ".join("%s=%s" % (nm, v) for (nm, _), v in zip(variants, combo)), ms.mean(), ms.min(),
+            n * d * el / ms.mean() / 1e9, n * d * el / ms.mean() / 8e9), flush=True)
