@@ -454,7 +454,7 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
         if (h->has_shadow) { h->shadow16.destroy(); h->has_shadow = false; }
         h->shadow_failed = true;
     }
-    ScanPlan p;
+    ScanPlan p = {};
     std::string err;
     // bound the partial-list buffer: process queries in batches
     int64_t done = 0;

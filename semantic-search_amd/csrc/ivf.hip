@@ -1031,7 +1031,7 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
             CHECK(ensure_ws(h, 2, (size_t)nb * nprobe * k * sizeof(skey_t)));
             CHECK(ensure_ws(h, 11, (size_t)(4 * h->nlist + 3) * 4 + (size_t)nb * 4));
             CHECK(ensure_ws(h, 12, (size_t)nb * nprobe * 4));
-            IvfListScanArgs A;
+            IvfListScanArgs A = {};
             A.X = R.view(); A.Q = qb; A.Ic = (const int64_t*)h->ws[7]; A.nq = nb; A.nprobe = nprobe; A.nlist = h->nlist;
             A.k = k; A.page_off = S->d_page_off; A.pages = S->d_pages; A.list_size = S->d_size; A.slot_ids = S->d_slot_ids;
             A.cnt = (int*)h->ws[11]; A.cursor = A.cnt + h->nlist; A.eoff = A.cursor + h->nlist + 1; A.uoff = A.eoff + h->nlist + 1;
@@ -1069,7 +1069,7 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
             HIPCHECK(hipGetLastError());
         }
         CHECK(ensure_ws(h, 2, (size_t)nb * gx * k * sizeof(skey_t)));
-        IvfScanParams P;
+        IvfScanParams P = {};
         P.X = R.view(); P.Q = qb; P.Ic = (const int64_t*)h->ws[7]; P.prefix = (const long long*)h->ws[10];
         P.po = (const int*)h->ws[13]; P.nsegs = (int)R.segs.size();
 #ifdef SSMI_IVF_STAMP

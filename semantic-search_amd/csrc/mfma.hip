@@ -91,7 +91,7 @@ hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, con
                        share_tops ? gtop : (unsigned*)nullptr, p.nslices * p.gtop_m);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    MfmaParams P;
+    MfmaParams P = {};
     P.X = X; P.Qh = (const _Float16*)qh; P.nq = nq; P.k = k; P.nqt = p.nqt; P.nslices = p.nslices;
     P.rows_per_slice = p.rows_per_slice; P.partial = partial; P.cand = (skey_t*)cand;
     P.gthr = (share_thr && p.nslices > 1) ? gthr : nullptr;

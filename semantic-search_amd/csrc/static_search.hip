@@ -85,7 +85,7 @@ int ssmi_index_search_static(ssmi_index* h, int64_t nq, const float* q_dev, int 
         return 0;
     }
     if (nq > (1ll << 20)) return fail("search_static: nq=%lld exceeds the maximum 1048576", (long long)nq);
-    ScanPlan p;
+    ScanPlan p = {};
     std::string err;
     if (!plan_flat_scan(R.dtype, R.ld, R.nrows, (int)nq, k, h->num_cu, &p, &err)) return fail("%s", err.c_str());
     const size_t need = (size_t)nq * p.grid_x * k * sizeof(skey_t);
