@@ -42,8 +42,12 @@ int RowStore::init(int d_, int dtype_) {
     // ~1 GiB segments, between 2^10 and 2^24 rows
     seg_shift = 10;
     while (seg_shift < 24 && (row_bytes << (seg_shift + 1)) <= ((size_t)1 << 30)) ++seg_shift;
-    const char* env = getenv("SSMI_SEG_SHIFT");  // tests use small segments to exercise the table
-    if (env) { int v = atoi(env); if (v >= 4 && v <= 24) seg_shift = v; }
+    // tests use small segments to exercise the table.  Never below 2^8 rows: the tile kernels (mfma_r128 / mfma_n128:
+    // 256-row tiles, ivf_lists_mfma: 32-slot pages) address a whole tile from its first row's segment, and slices start
+    // at multiples of 256 rows, so a segment must hold whole tiles (found by tests/test_fuzz_gpu.py with 64-row
+    // segments: reads past the end of a segment)
+    const char* env = getenv("SSMI_SEG_SHIFT");
+    if (env) { int v = atoi(env); if (v >= 8 && v <= 24) seg_shift = v; }
     nrows = 0;
     seg0_cap = 0;
     HIPCHECK(hipMalloc((void**)&d_segs, sizeof(void*) * kMaxSegs));
