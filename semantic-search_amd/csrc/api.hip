@@ -33,7 +33,7 @@ int fail(const char* fmt, ...) {
 // ---------------------------------------------------------------------------
 namespace ssmi {
 
-int RowStore::init(int d_, int dtype_) {
+int RowStore::init(int d_, int dtype_, hipStream_t stream) {
     d = d_;
     dtype = dtype_;
     elsize = dtype == SSMI_F32 ? 4 : 2;
@@ -51,7 +51,7 @@ int RowStore::init(int d_, int dtype_) {
     nrows = 0;
     seg0_cap = 0;
     HIPCHECK(hipMalloc((void**)&d_segs, sizeof(void*) * kMaxSegs));
-    HIPCHECK(hipMemset(d_segs, 0, sizeof(void*) * kMaxSegs));
+    HIPCHECK(zero_device_sync(d_segs, sizeof(void*) * kMaxSegs, stream));
     return 0;
 }
 
@@ -181,10 +181,10 @@ static int create_common(int d, int storage_dtype, int device, int kind, ssmi_in
         for (int j = 0; j < 3; ++j) HIPCHECK(hipEventCreate(&h->ev[i][j]));
     if (!getenv("SSMI_NO_TAIL")) {
         HIPCHECK(hipMalloc((void**)&h->tail_counters, ssmi_index::kTailCounters * sizeof(unsigned)));
-        HIPCHECK(hipMemset(h->tail_counters, 0, ssmi_index::kTailCounters * sizeof(unsigned)));
+        HIPCHECK(zero_device_sync(h->tail_counters, ssmi_index::kTailCounters * sizeof(unsigned), h->stream));
     }
     if (const char* e = getenv("SSMI_TIMING")) h->timing_on = e[0] != '0';
-    CHECK(h->rows.init(d, storage_dtype));
+    CHECK(h->rows.init(d, storage_dtype, h->stream));
     guard.h = nullptr;
     *out = h;
     return 0;
@@ -443,7 +443,7 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
         // bring the fp16 shadow up to date, then run the MFMA contraction on it.  A shadow that does not fit in
         // HBM is not an error of the search: it is dropped and this and later batches stay on the exact scan.
         auto bring_up = [&]() -> int {
-            if (!h->has_shadow) { CHECK(h->shadow16.init(R.d, SSMI_F16)); h->has_shadow = true; }
+            if (!h->has_shadow) { CHECK(h->shadow16.init(R.d, SSMI_F16, s)); h->has_shadow = true; }
             RowStore& S = h->shadow16;
             if (S.nrows < R.nrows) {
                 CHECK(S.reserve(R.nrows, s));
@@ -768,7 +768,10 @@ int ssmi_index_get_timing(const ssmi_index* h, ssmi_timing* out) {
         // per-query IVF scan: rows probed by the first query of the last search (its prefix-sum total)
         long long rows = 0;
         const int nprobe = std::min(h->nprobe, h->nlist);
-        HIPCHECK(hipMemcpy(&rows, (const long long*)h->ws[10] + nprobe, sizeof rows, hipMemcpyDeviceToHost));
+        // on the stream of the search that wrote it (a copy on the NULL stream is not ordered against other streams)
+        hipStream_t ls = h->have_last_search ? h->last_search_stream : h->stream;
+        HIPCHECK(hipMemcpyAsync(&rows, (const long long*)h->ws[10] + nprobe, sizeof rows, hipMemcpyDeviceToHost, ls));
+        HIPCHECK(hipStreamSynchronize(ls));
         t.last_scan_bytes = rows * (int64_t)h->rows.d * (int64_t)h->rows.elsize;
         t.last_scan_flops = 2 * rows * (int64_t)h->rows.d;
     }

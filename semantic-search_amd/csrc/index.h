@@ -25,7 +25,7 @@ struct RowStore {
     std::vector<void*> segs;
     void** d_segs = nullptr;
 
-    int init(int d, int dtype);
+    int init(int d, int dtype, hipStream_t stream);  // `stream`: where the segment table is zeroed (see zero_device_sync)
     void destroy();
     int reserve(long long total_rows, hipStream_t stream);
     RowView view() const;
@@ -82,6 +82,15 @@ struct ssmi_index {
     long long ivf_slots_used = 0;  // slots handed out in `rows` (pages * page_rows)
     void* ivf = nullptr;           // ssmi::IvfState*
 };
+
+// Zero device memory ON `stream` and wait for it.  Not hipMemset: that runs on the NULL stream, and the handles' own
+// streams are non-blocking, i.e. not ordered against it - with a caller's search still in flight on the NULL stream
+// (torch's default stream) the zeros would land AFTER what the handle's stream wrote into the same buffer in the
+// meantime (found by tests/test_fuzz_api_gpu.py: a new index's segment table zeroed behind its first add).
+inline hipError_t zero_device_sync(void* p, size_t bytes, hipStream_t stream) {
+    const hipError_t e = hipMemsetAsync(p, 0, bytes, stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(stream);
+}
 
 #define HIPCHECK(expr)                                                                             \
     do {                                                                                           \

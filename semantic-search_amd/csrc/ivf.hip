@@ -486,14 +486,14 @@ int ivf_create(ssmi_index* h, int nlist) {
     h->nlist = nlist;
     h->nprobe = 1;  // FAISS default
     h->trained = false;
-    if (S->cent32.init(h->rows.d, SSMI_F32)) return 1;
-    if (S->cent16.init(h->rows.d, SSMI_F16)) return 1;
+    if (S->cent32.init(h->rows.d, SSMI_F32, h->stream)) return 1;
+    if (S->cent16.init(h->rows.d, SSMI_F16, h->stream)) return 1;
     S->pages.assign(nlist, {});
     S->size.assign(nlist, 0);
     HIPCHECK(hipMalloc((void**)&S->d_page_off, sizeof(int) * (nlist + 1)));
     HIPCHECK(hipMalloc((void**)&S->d_size, sizeof(int) * nlist));
-    HIPCHECK(hipMemset(S->d_page_off, 0, sizeof(int) * (nlist + 1)));
-    HIPCHECK(hipMemset(S->d_size, 0, sizeof(int) * nlist));
+    HIPCHECK(zero_device_sync(S->d_page_off, sizeof(int) * (nlist + 1), h->stream));
+    HIPCHECK(zero_device_sync(S->d_size, sizeof(int) * nlist, h->stream));
     return 0;
 }
 
@@ -917,7 +917,7 @@ int ivf_add_random_unit(ssmi_index* h, int64_t n, uint64_t seed) {
     // generate into a scratch flat store chunk by chunk, then route through the normal add path
     const RowStore& R = h->rows;
     RowStore tmp;
-    if (tmp.init(R.d, SSMI_F32)) return 1;
+    if (tmp.init(R.d, SSMI_F32, h->stream)) return 1;
     struct D { RowStore* s; ~D() { s->destroy(); } } guard{&tmp};
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(1 << 16, ((size_t)1 << 30) / ((size_t)R.ld * 4)));
     if (chunk > (1ll << tmp.seg_shift)) return fail("internal: chunk exceeds scratch segment");
@@ -997,7 +997,7 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
                       ivf_list_mfma_supported(SSMI_F16, R.ld, k) && !(env_lmm && env_lmm[0] == '0');
     if (via_shadow && !h->has_shadow) {
         auto bring_up = [&]() -> int {
-            CHECK(h->shadow16.init(R.d, SSMI_F16));
+            CHECK(h->shadow16.init(R.d, SSMI_F16, s));
             h->has_shadow = true;
             CHECK(h->shadow16.reserve(R.nrows, s));
             RowView src = R.view();
