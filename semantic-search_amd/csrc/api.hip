@@ -555,7 +555,9 @@ int ssmi_index_search_min(ssmi_index* h, int64_t nq, const float* q, int q_mem_k
     // stream (NULL then means the HIP null stream, e.g. torch's default stream)
     const bool any_dev = q_mem_kind == SSMI_DEVICE || out_mem_kind == SSMI_DEVICE;
     hipStream_t s = (stream || any_dev) ? (hipStream_t)stream : h->stream;
-    if (h->kind == SSMI_KIND_IVFFLAT && !h->trained) return fail("search on an untrained IVF index");
+    // An untrained IVF index holds nothing (add refuses until train): like FAISS, whose IndexIVF::search does not test
+    // is_trained and finds no list to probe, the search returns the "no result" padding.  The reference searches
+    // without a guard while an IVF index still buffers its training vectors (core/index_manager.py:371).
     CHECK(order_search_on(h, s));
 
     float* Ddev = D;
@@ -587,7 +589,7 @@ int ssmi_index_search_min(ssmi_index* h, int64_t nq, const float* q, int q_mem_k
         if (h->pin_bytes >= q_bytes + out_bytes) pin = (unsigned char*)h->pin;
     }
     const int64_t ntotal = h->kind == SSMI_KIND_FLAT ? h->rows.nrows : h->ivf_ntotal;
-    if (ntotal == 0) {
+    if (ntotal == 0 || (h->kind == SSMI_KIND_IVFFLAT && !h->trained)) {
         HIPCHECK(launch_fill_empty(Ddev, Idev, nq * k, s));
     } else {
         const float* qdev = nullptr;

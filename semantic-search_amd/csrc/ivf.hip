@@ -573,6 +573,15 @@ static int assign_to_centroids_host(ssmi_index* h, int64_t n, const float* xdev,
     return 0;
 }
 
+// The quantizer changed (trained, centroids replaced): a base file written before describes another index, so the next
+// incremental checkpoint must be a full write, not a journal record on top of it (found by
+// tests/test_fuzz_manager_gpu.py: saved while buffering, trained, saved again, reloaded untrained).
+static void forget_persisted_state(IvfState* S) {
+    S->persist_path.clear();
+    S->persist_base_ntotal = -1;
+    S->persist_journal_rows = 0;
+}
+
 int install_centroids(ssmi_index* h, const float* c, int mem_kind) {
     IvfState* S = st(h);
     S->cent32.nrows = 0;
@@ -580,6 +589,7 @@ int install_centroids(ssmi_index* h, const float* c, int mem_kind) {
     CHECK(store_add(h, S->cent32, h->nlist, c, SSMI_F32, mem_kind));
     CHECK(store_add(h, S->cent16, h->nlist, c, SSMI_F32, mem_kind));
     h->trained = true;
+    forget_persisted_state(S);
     return 0;
 }
 
@@ -678,6 +688,7 @@ int ivf_train(ssmi_index* h, int64_t n, const float* x, int mem_kind) {
         HIPCHECK(hipStreamSynchronize(h->stream));
     }
     h->trained = true;
+    forget_persisted_state(S);
     return 0;
 }
 

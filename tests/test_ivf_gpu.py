@@ -96,8 +96,8 @@ def test_train_kmeans_quality_and_recall(ssa):
     index = make_ivf(ssa, d, nlist)
     with pytest.raises(RuntimeError):
         index.add(X[:10])           # untrained
-    with pytest.raises(RuntimeError):
-        index.search(X[:1], 5)
+    D0, I0 = index.search(X[:2], 5)   # FAISS: IndexIVF::search does not test is_trained; no list to probe, no result
+    assert (I0 == -1).all() and (D0 == flat_ip.NEG_MAX).all()
     with pytest.raises(RuntimeError):
         index.train(X[:10])         # fewer points than clusters
     assert not index.is_trained

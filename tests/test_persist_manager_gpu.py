@@ -352,3 +352,32 @@ def test_search_multi_index_merges_like_the_node(ssa, tmp_path):
     c.add_vectors(X[:2], ["/gone/0.jpg", str(real)], ["", ""], [(0.0, 0)] * 2)
     assert [r.file_path for r in c.search(X[0], top_k=2)] == [str(real)]
     c.close()
+
+
+def test_checkpoint_after_training_rewrites_the_base(ssa, tmp_path):
+    """An IVF index checkpointed while untrained (the reference saves every 10 batches, also while it still buffers
+    training vectors), trained later and checkpointed again must not leave the untrained base file with the members
+    in a journal on top: the quantizer changed, so the incremental write becomes a full one."""
+    d, nlist = 48, 6
+    X = unit_rows(500, d, 77)
+    ix = ssa.IndexIVFFlat(ssa.IndexFlatIP(d), d, nlist, ssa.METRIC_INNER_PRODUCT)
+    p = tmp_path / "vectors.faiss"
+    ssa.write_index(ix, p, incremental=True)              # untrained, empty
+    back = ssa.read_index(p)
+    assert not back.is_trained and back.ntotal == 0
+    D, I = back.search(X[:3], 5)                          # FAISS: no list to probe -> no result, no exception
+    assert (I == -1).all()
+    ix.train(X); ix.add(X)
+    ssa.write_index(ix, p, incremental=True)
+    back = ssa.read_index(p)
+    assert back.is_trained and back.ntotal == 500
+    np.testing.assert_array_equal(back.get_centroids(), ix.get_centroids())
+    ix.nprobe = back.nprobe = nlist
+    D0, I0 = ix.search(X[:7], 10); D1, I1 = back.search(X[:7], 10)
+    np.testing.assert_array_equal(I0, I1); np.testing.assert_array_equal(D0, D1)
+    # replaced centroids invalidate the base as well
+    ix2 = ssa.IndexIVFFlat(ssa.IndexFlatIP(d), d, nlist, ssa.METRIC_INNER_PRODUCT)
+    ix2.set_centroids(unit_rows(nlist, d, 78)); ix2.add(X[:100])
+    ssa.write_index(ix2, p)
+    ix2.add(X[100:200]); ssa.write_index(ix2, p, incremental=True)
+    assert ssa.read_index(p).ntotal == 200
