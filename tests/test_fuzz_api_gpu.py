@@ -138,3 +138,40 @@ def test_floor_and_device_io_sweep(ssa, seed):
     np.testing.assert_array_equal(Io.cpu().numpy(), exp, err_msg=case)
     np.testing.assert_array_equal(Do.cpu().numpy(), D0, err_msg=case)
     ix.close()
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_readback_sweep(ssa, seed):
+    """reconstruct / reconstruct_n / reconstruct_batch(_device) / score_ids on Flat and IVF (with a direct map) give the
+    stored rows (fp16-rounded under f16 storage) and their inner products; ids out of range are an error, not a read."""
+    rng = np.random.default_rng(7000 + seed)
+    kind = str(rng.choice(["flat", "ivf"]))
+    d = int(rng.choice([8, 100, 256, 4096]))
+    storage = str(rng.choice(["f32", "f16"]))
+    n = int(rng.choice([1, 33, 700, 5000]))
+    X = unit_rows(n, d, 7100 + seed)
+    Xs = X.astype(np.float16).astype(np.float32) if storage == "f16" else X
+    ix = _index(ssa, kind, d, storage, int(rng.choice([1, 5, 30])), seed)
+    if kind == "ivf":
+        with pytest.raises(RuntimeError):
+            ix.add(X[:1]); ix.reconstruct(0)          # no direct map yet (FAISS raises too)
+        ix.make_direct_map()
+        ix.add(X[1:])
+    else:
+        ix.add(X)
+    case = f"seed={seed} {kind} d={d} {storage} n={n}"
+    ids = rng.integers(0, n, size=int(rng.choice([1, 7, 300])))
+    np.testing.assert_array_equal(ix.reconstruct_batch(ids), Xs[ids], err_msg=case)
+    np.testing.assert_array_equal(ix.reconstruct_batch_device(ids).cpu().numpy(), Xs[ids], err_msg=case)
+    np.testing.assert_array_equal(ix.reconstruct(int(ids[0])), Xs[ids[0]], err_msg=case)
+    if kind == "flat":
+        a = int(rng.integers(0, n)); b = int(rng.integers(a, n + 1))
+        np.testing.assert_array_equal(ix.reconstruct_n(a, b - a), Xs[a:b], err_msg=case)
+    neg = unit_rows(int(rng.choice([1, 3])), d, 7200 + seed)
+    np.testing.assert_allclose(ix.score_ids(ids, neg), Xs[ids] @ neg.T, rtol=1e-5, atol=1e-6, err_msg=case)
+    for bad in ([-1], [n], [0, n + 5]):
+        with pytest.raises(RuntimeError):
+            ix.reconstruct_batch(bad)
+        with pytest.raises(RuntimeError):
+            ix.score_ids(bad, neg)
+    ix.close()

@@ -130,3 +130,29 @@ def test_ivf_sweep(ssa, monkeypatch, seed):
         ok = True
     assert ok, f"{case} kernel={kernel}: {msg}"
     index.close()
+
+
+@pytest.mark.parametrize("n,d,nq,k,storage", [
+    (300, 64, 5000, 10, "f16"),       # more queries than one MFMA launch takes over a small store (65536 per launch)
+    (70000, 64, 4500, 5, "f16"),      # ... and over a large one (4096 per launch): two launches, two merges
+    (70000, 64, 4500, 5, "f32"),      # the same through the fp16 shadow
+    (2000, 256, 3000, 300, "f32"),    # exact scan with a wide k: the partial-list buffer bounds the queries per pass
+])
+def test_query_batches_beyond_one_launch(ssa, monkeypatch, n, d, nq, k, storage):
+    if storage == "f32" and k == 300:
+        monkeypatch.setenv("SSMI_NO_SHADOW", "1")
+    X, Q = unit_rows(n, d, 31), unit_rows(nq, d, 32)
+    index = ssa.IndexFlatIP(d, storage=storage)
+    index.add(X)
+    D, I = index.search(Q, k)
+    path = index.last_timing()["last_path"]
+    Xs = r16(X) if storage == "f16" else X
+    if path == 1 and storage == "f32":
+        Dr, Ir = flat_ip.search(X, Q, k)
+        ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, X, Q, rtol=1e-3, tie_rtol=1e-3, atol=6 * 2.0 ** -11 * np.sqrt(2.0 / d))
+    else:
+        Qs = r16(Q) if path == 1 else Q
+        Dr, Ir = flat_ip.search(Xs, Qs, k)
+        ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xs, Qs, rtol=1e-5, tie_rtol=1e-5)
+    assert ok, f"path={path} kernel={index.last_kernel()}: {msg}"
+    index.close()

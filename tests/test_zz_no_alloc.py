@@ -116,3 +116,29 @@ def test_static_search_makes_no_device_allocation(ssa):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free1 == free0
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_static_search_sweep(ssa, monkeypatch, seed):
+    """Seeded shapes: both entry points on the streaming scan (the batched one is kept off the matrix cores) must agree
+    bit for bit, call after call on the shared array; a request beyond the array is refused with a message."""
+    import torch
+    monkeypatch.setenv("SSMI_MFMA_MIN_B", "1000000")
+    rng = np.random.default_rng(9000 + seed)
+    d = int(rng.choice([8, 64, 256, 1000, 1024, 4096]))
+    storage = str(rng.choice(["f32", "f16"]))
+    n = int(rng.choice([1, 70, 257, 3000, 20000]))
+    index = ssa.IndexFlatIP(d, storage=storage, fp16_shadow=False)
+    index.add(unit_rows(n, d, 9100 + seed))
+    for call in range(3):
+        nq = int(rng.choice([1, 2, 3, 8, 9, 40]))
+        k = int(rng.choice([1, 10, 64, 65, 300, 1024]))
+        Qd = torch.from_numpy(unit_rows(nq, d, 9200 + seed * 7 + call)).cuda()
+        try:
+            D0, I0, D1, I1 = _pair(ssa, index, Qd, k, id_offset=int(rng.choice([0, 77])))
+        except RuntimeError as e:
+            assert "static scratch" in str(e), e     # nq x row slices x k keys beyond the 8 MiB array
+            continue
+        np.testing.assert_array_equal(I1, I0, err_msg=f"seed={seed} call={call} n={n} d={d} {storage} nq={nq} k={k}")
+        np.testing.assert_array_equal(D1, D0, err_msg=f"seed={seed} call={call} n={n} d={d} {storage} nq={nq} k={k}")
+    index.close()
