@@ -53,8 +53,14 @@ def gather_packed(buf: torch.Tensor, B: int, k: int, group=None) -> Tuple[torch.
     """all_gather the packed per-rank buffers; returns strided (world, B, k) views of scores and ids."""
     world = dist.get_world_size(group)
     words = buf.numel()
-    g = torch.empty((world * words,), dtype=torch.int64, device=buf.device)
-    dist.all_gather_into_tensor(g, buf, group=group)
+    if buf.is_cuda and dist.get_backend(group) != "nccl":
+        # a host-only backend (gloo: ranks that share one GPU, tools/two_rank_check.py): the collective runs on host copies
+        gh = torch.empty((world * words,), dtype=torch.int64)
+        dist.all_gather_into_tensor(gh, buf.cpu(), group=group)
+        g = gh.to(buf.device)
+    else:
+        g = torch.empty((world * words,), dtype=torch.int64, device=buf.device)
+        dist.all_gather_into_tensor(g, buf, group=group)
     g = g.view(world, words)
     n = B * k
     Ig = g[:, :n].unflatten(1, (B, k))
