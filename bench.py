@@ -69,6 +69,11 @@ class Dist:
         # sharded search with its RCCL all-gather, routed IVF add) on a single rank
         self.on = self.world > 1 or os.environ.get("SSMI_BENCH_FORCE_DIST") == "1"
         self.forced = self.on and self.world == 1
+        # SSMI_BENCH_SHARE_GPU=1: rehearsal of a multi-rank run on a ONE-GPU box - every rank uses GPU 0 and the ranks
+        # talk over gloo (RCCL refuses two ranks on one device); the numbers of such a run mean nothing, the code path does
+        self.share = os.environ.get("SSMI_BENCH_SHARE_GPU") == "1"
+        if self.share:
+            self.local_rank = 0
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
         if self.on:
@@ -78,7 +83,10 @@ class Dist:
             saved = os.dup(1)
             os.dup2(2, 1)
             try:
-                dist.init_process_group("nccl", device_id=self.dev)
+                if self.share:
+                    dist.init_process_group("gloo")
+                else:
+                    dist.init_process_group("nccl", device_id=self.dev)
                 dist.barrier()
                 torch.cuda.synchronize()
             finally:
