@@ -98,6 +98,7 @@ hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, con
     P.gtop = share_tops ? gtop : nullptr;
     P.gtop_m = p.gtop_m;
     P.thr_floor = min_ord ? ord_to_f32(min_ord) : SSMI_NEG_MAX;
+    { const char* e = getenv("SSMI_MFMA_SEED_FIRST"); P.seed_first = !(e && e[0] == '0'); }
     int r = 1;
     while (64 * r < k) r <<= 1;
     if (p.narrow) {

@@ -27,6 +27,7 @@ struct MfmaParams {
     // query is a lower bound of its final k-th score - far tighter than any single slice's own k-th score
     unsigned* gtop;
     int gtop_m;
+    int seed_first;            // 256-query kernel, k <= 16: the first row tile of a slice seeds its own threshold
 #ifdef SSMI_STAMP
     unsigned long long* dbg;   // diagnostic build only: per-wave cycle sums
 #endif
@@ -334,7 +335,8 @@ __device__ __forceinline__ float vmax2(float a, float b) {
 template <int MT, int NT, bool FULL>
 __device__ __forceinline__ void filter_tile(const f32x4_t (&acc)[MT][NT], int row_base, int q_base, int frow, int fq,
                                             long long row0, int rows_valid, skey_t* cand, const float* thr_l,
-                                            unsigned* cnt_l, unsigned* flag_l, const uint32_t* ids = nullptr) {
+                                            unsigned* cnt_l, unsigned* flag_l, const uint32_t* ids = nullptr,
+                                            bool seed16 = false) {
     // ids == nullptr: the id of row rr of the tile is row0 + rr (Flat).  Otherwise ids[rr - row_base] (IVF: the
     // wave's rows are the slots of one list page, whose vector ids are looked up only for survivors).
     // acc[m][n]: rows row_base + m*16 + fq*4 + i of the row tile, query q_base + n*16 + frow of the query tile.
@@ -344,7 +346,28 @@ __device__ __forceinline__ void filter_tile(const f32x4_t (&acc)[MT][NT], int ro
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int ql = q_base + n * 16 + frow;
-        const float thr = thr_l[ql];
+        float thr = thr_l[ql];
+        if (FULL && seed16) {
+            // First row tile of a slice, k <= 16 (wave-uniform flag): no list exists yet, so every row would pass the
+            // filter and the first fold would sort MT*16*4*(waves per column) candidates per query.  The 4th largest of
+            // a lane's values, minimised over the four lanes that share the column, has at least 16 of THIS wave's
+            // rows at or above it: every row of the tile's best 16 that lies in this wave's rows is among them, so it
+            // may serve as this wave's threshold for this tile (whole tiles only: padding rows repeat a row).
+            float a0 = -__builtin_inff(), a1 = a0, a2 = a0, a3 = a0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = acc[m][n][i];
+                    const float t = fminf(v, a0); a0 = fmaxf(v, a0);
+                    const float u = fminf(t, a1); a1 = fmaxf(t, a1);
+                    const float w = fminf(u, a2); a2 = fmaxf(u, a2);
+                    a3 = fmaxf(w, a3);
+                }
+            a3 = fminf(a3, __int_as_float(xor_lane<16>(__float_as_int(a3))));
+            a3 = fminf(a3, __int_as_float(xor_lane<32>(__float_as_int(a3))));
+            thr = fmaxf(thr, a3);
+        }
         float mm[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) mm[m] = vmax2(vmax3(acc[m][n][0], acc[m][n][1], acc[m][n][2]), acc[m][n][3]);

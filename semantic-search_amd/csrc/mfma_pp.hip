@@ -280,7 +280,9 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
             continue;
         }
         // ---- epilogue: threshold filter, survivors -> candidate buffers ----
-        if (left >= TM) filter_tile<8, 4, true>(acc, wm * 128, wn * 64, frow, fq, row0, TM, cand, thr_l, cnt_l, flag_l);
+        // (first tile of the slice, k <= 16: the tile seeds its own threshold - see filter_tile)
+        if (left >= TM) filter_tile<8, 4, true>(acc, wm * 128, wn * 64, frow, fq, row0, TM, cand, thr_l, cnt_l, flag_l, nullptr,
+                                                tiles_done == 0 && P.k <= 16 && P.seed_first);
         else filter_tile<8, 4, false>(acc, wm * 128, wn * 64, frow, fq, row0, (int)left, cand, thr_l, cnt_l, flag_l);
         STAMP(3)
         __syncthreads();
