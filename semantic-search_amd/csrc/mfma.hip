@@ -99,6 +99,10 @@ hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, con
     P.gtop_m = p.gtop_m;
     P.thr_floor = min_ord ? ord_to_f32(min_ord) : SSMI_NEG_MAX;
     { const char* e = getenv("SSMI_MFMA_SEED_FIRST"); P.seed_first = !(e && e[0] == '0'); }
+    // scheduled folds after row tiles 1, 4, 16, 64, ... of a slice; with the cross-slice bound (which matures much faster
+    // than a slice's own k-th score) after 1, 16, 256, ... only (SSMI_MFMA_FOLD_MASK: bit b = a fold after tile 2^b)
+    P.fold_mask = P.gtop ? 0x11111111u : 0x55555555u;
+    if (const char* e = getenv("SSMI_MFMA_FOLD_MASK")) P.fold_mask = (unsigned)strtoul(e, nullptr, 16) | 1u;
     int r = 1;
     while (64 * r < k) r <<= 1;
     if (p.narrow) {

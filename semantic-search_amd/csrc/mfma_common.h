@@ -28,6 +28,7 @@ struct MfmaParams {
     unsigned* gtop;
     int gtop_m;
     int seed_first;            // 256-query kernel, k <= 16: the first row tile of a slice seeds its own threshold
+    unsigned fold_mask;        // 256-query kernel: a scheduled fold follows row tile 2^b of the slice when bit b is set
 #ifdef SSMI_STAMP
     unsigned long long* dbg;   // diagnostic build only: per-wave cycle sums
 #endif

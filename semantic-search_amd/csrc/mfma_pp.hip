@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
     // nslices) and pushes it into gthr; another row tile later every wave pulls gthr for its queries.
     // scheduled folds after row tiles 1, 4, 16, 64, ...; with the cross-slice bound (which matures much faster than a
     // slice's own k-th score) after 1, 16, 256, ... only
-    const unsigned fold_mask = P.gtop ? 0x11111111u : 0x55555555u;
+    const unsigned fold_mask = P.fold_mask;
     int xstate = 0;  // 1: push bounds at the next tile end, 2: pull thresholds at the next tile end
     auto push_bounds = [&]() {
         for (int ql = slice + wave * P.nslices; ql < 256 && q0 + ql < P.nq; ql += 8 * P.nslices) {
