@@ -233,6 +233,10 @@ __device__ __forceinline__ unsigned lds_add_rtn(unsigned* p, unsigned v) {
     asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(addr), "v"(v) : "memory");
     return old;
 }
+__device__ __forceinline__ void lds_min_u32(unsigned* p, unsigned v) {
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned*)p;
+    asm volatile("ds_min_u32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(addr), "v"(v) : "memory");
+}
 __device__ __forceinline__ void lds_store(unsigned* p, unsigned v) {
     const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned*)p;
     asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(addr), "v"(v) : "memory");

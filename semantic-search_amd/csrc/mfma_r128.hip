@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
     unsigned* cnt_l = reinterpret_cast<unsigned*>(thr_l + N128_TN);
     unsigned* kept_l = cnt_l + N128_TN;
     unsigned* flag_l = kept_l + N128_TN;
+    unsigned* seed_l = flag_l + 4;  // [N128_TN] first-tile threshold seeds (f32_to_ord bits, minimum over the waves)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -49,6 +50,7 @@ __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
         thr_l[tid] = (tid < P.nq) ? P.thr_floor : __builtin_inff();
         cnt_l[tid] = 0;
         kept_l[tid] = 0;
+        seed_l[tid] = 0xFFFFFFFFu;
     }
     if (tid == 0) *flag_l = 0;
     __syncthreads();
@@ -193,6 +195,39 @@ __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
 
         // ---- row tile complete: threshold filter; fold the candidate buffers when due ----
         const long long left = r_end - row0;
+        if (t == 0 && left >= TM && P.k <= 16 && P.seed_first) {
+            // The first row tile seeds the thresholds (k <= 16, whole tile): a slice starts without a list, so all 256
+            // rows would pass the filter and the first fold would sort 256 candidates per query.  Every wave takes the
+            // SECOND largest score of its 32 rows per query; the minimum of those over the 8 waves has at least 16 rows
+            // of the tile at or above it, i.e. it is a lower bound of the final k-th score and a legitimate threshold.
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                float a1 = -__builtin_inff(), a2 = a1;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = acc[m][n][i];
+                        const float lo = fminf(v, a1);
+                        a1 = fmaxf(v, a1);
+                        a2 = fmaxf(a2, lo);
+                    }
+                {   // the four lanes (fq) that hold the other rows of this query column
+                    float b1 = __int_as_float(xor_lane<16>(__float_as_int(a1))), b2 = __int_as_float(xor_lane<16>(__float_as_int(a2)));
+                    a2 = fmaxf(fminf(a1, b1), fmaxf(a2, b2)); a1 = fmaxf(a1, b1);
+                    b1 = __int_as_float(xor_lane<32>(__float_as_int(a1))); b2 = __int_as_float(xor_lane<32>(__float_as_int(a2)));
+                    a2 = fmaxf(fminf(a1, b1), fmaxf(a2, b2)); a1 = fmaxf(a1, b1);
+                }
+                if (fq == 0) lds_min_u32(&seed_l[n * 16 + frow], f32_to_ord(a2));
+            }
+            __builtin_amdgcn_s_barrier();
+            if (tid < N128_TN && tid < P.nq) {
+                const float sd = ord_to_f32(seed_l[tid]);
+                if (sd > thr_l[tid]) lds_store(reinterpret_cast<unsigned*>(&thr_l[tid]), __float_as_uint(sd));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         if (left >= TM) filter_tile<2, NT, true>(acc, wave * 32, 0, frow, fq, row0, TM, cand, thr_l, cnt_l, flag_l);
         else filter_tile<2, NT, false>(acc, wave * 32, 0, frow, fq, row0, (int)left, cand, thr_l, cnt_l, flag_l);
 #pragma unroll
@@ -245,7 +280,7 @@ __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
 
 template <int PD, int NT>
 static hipError_t launch_pd(const MfmaParams& P, int r, int grid, hipStream_t s) {
-    const size_t lds = (size_t)(PD + 1) * RQ_SLOT + 3 * N128_TN * 4 + 16;
+    const size_t lds = (size_t)(PD + 1) * RQ_SLOT + 4 * N128_TN * 4 + 16;
     hipError_t e;
 #define LAUNCH_R(RR)                                                                                    \
     case RR: {                                                                                          \
