@@ -156,3 +156,56 @@ def test_query_batches_beyond_one_launch(ssa, monkeypatch, n, d, nq, k, storage)
         ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xs, Qs, rtol=1e-5, tie_rtol=1e-5)
     assert ok, f"path={path} kernel={index.last_kernel()}: {msg}"
     index.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_ivf_grow_and_search_walk(ssa, monkeypatch, seed):
+    """One IVF index that keeps growing (the reference adds 16 vectors at a time) while it is searched with changing
+    batch sizes, k and nprobe: per-query scans, list-major scans and (fp16 rows, or the fp16 shadow of fp32 lists) the
+    matrix-core scan all read the same page tables, which every add extends; after each step the result must match the
+    oracle run on the index's own assignment of everything added so far."""
+    rng = np.random.default_rng(2500 + seed)
+    d = int(rng.choice([64, 512, 1024, 4096]))
+    nlist = int(rng.choice([4, 16, 50]))
+    storage = str(rng.choice(["f32", "f16"]))
+    cen = unit_rows(nlist, d, 2600 + seed)
+    pool = cen[rng.integers(0, nlist, 5000)] + 0.6 * unit_rows(5000, d, 2700 + seed)
+    pool = (pool / np.linalg.norm(pool, axis=1, keepdims=True)).astype(np.float32)
+    index = ssa.IndexIVFFlat(ssa.IndexFlatIP(d, storage=storage), d, nlist, ssa.METRIC_INNER_PRODUCT, storage=storage)
+    index.set_centroids(cen)
+    at = 0
+    for step in range(14):
+        grow = int(rng.choice([1, 16, 16, 40, 400, 1500]))
+        grow = min(grow, len(pool) - at)
+        if grow:
+            index.add(pool[at:at + grow]); at += grow
+        nq = int(rng.choice([1, 3, 9, 20, 70, 200]))
+        k = int(rng.choice([1, 10, 100, 256]))
+        nprobe = int(rng.choice([1, 3, nlist]))
+        index.nprobe = nprobe
+        Q = unit_rows(nq, d, 2800 + seed * 31 + step)
+        D, I = index.search(Q, k)
+        case = f"seed={seed} step={step} d={d} nlist={nlist} {storage} n={at} nq={nq} k={k} nprobe={nprobe} kernel={index.last_kernel()}"
+        labels = index.assignments()
+        assert len(labels) == at and index.ntotal == at, case
+        X = pool[:at]
+        mfma = "mfma" in index.last_kernel()
+        Xs = r16(X) if (storage == "f16" or mfma) else X
+        Qs = r16(Q) if mfma else Q
+        coarse = dict(C_coarse=r16(cen), Q_coarse=r16(Q)) if (nq >= 9 and d % 64 == 0) else {}
+        Dr, Ir, _ = ivf_flat.search(Xs, cen, labels, Qs, k, min(nprobe, nlist), **coarse)
+        tol = 1e-3 if (mfma and storage == "f32") else 1e-5
+        ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xs, Qs, rtol=tol, tie_rtol=tol, atol=2e-6 if tol < 1e-4 else 6 * 2.0 ** -11 * np.sqrt(2.0 / d))
+        if not ok and coarse and nprobe < nlist:
+            # fp16-ranked probe lists may swap two near-tied centroids at the probe boundary: every hit must then still
+            # come from a list within rounding of the nprobe-th best, with its exact score
+            sc = Q @ cen.T
+            kth = np.sort(sc, axis=1)[:, -min(nprobe, nlist)][:, None]
+            near = sc >= kth - 2e-3
+            for qi in range(nq):
+                ids = I[qi][I[qi] >= 0]
+                assert near[qi][labels[ids]].all(), f"{case}: {msg}"
+                np.testing.assert_allclose(D[qi][:len(ids)], Xs[ids] @ Qs[qi], rtol=1e-4, atol=1e-5, err_msg=case)
+            ok = True
+        assert ok, f"{case}: {msg}"
+    index.close()
