@@ -175,3 +175,51 @@ def test_readback_sweep(ssa, seed):
         with pytest.raises(RuntimeError):
             ix.score_ids(bad, neg)
     ix.close()
+
+
+def test_threads_with_their_own_indexes_streams_and_lifetimes(ssa):
+    """ComfyUI calls the engine from several threads, each on its own index (core/index_manager.py:1481-1504): eight
+    threads create, grow, search (numpy route, or device tensors on a stream of their own) and free indexes of their own
+    at the same time; every search is checked against numpy on the thread's own rows."""
+    import threading
+    import torch
+    errors = []
+
+    def worker(t):
+        try:
+            rng = np.random.default_rng(100 + t)
+            stream = torch.cuda.Stream() if t % 2 else None
+            for rep in range(6):
+                d = int(rng.choice([64, 256, 1024]))
+                storage = "f32" if t % 4 < 2 else "f16"
+                X = unit_rows(int(rng.choice([50, 700, 3000])), d, 1000 * t + rep)
+                Xs = X.astype(np.float16).astype(np.float32) if storage == "f16" else X
+                ix = ssa.IndexFlatIP(d, storage=storage)
+                at = 0
+                while at < len(X):
+                    step = int(rng.choice([16, 200, 1000]))
+                    ix.add(X[at:at + step]); at = min(len(X), at + step)
+                    Q = unit_rows(int(rng.choice([1, 3])), d, 7 * t + at)
+                    if stream is None:
+                        D, I = ix.search(Q, 5)
+                    else:
+                        with torch.cuda.stream(stream):
+                            Dd, Id = ix.search(torch.from_numpy(Q).cuda(), 5)
+                        stream.synchronize()
+                        D, I = Dd.cpu().numpy(), Id.cpu().numpy()
+                    S = Q @ Xs[:at].T
+                    for qi in range(len(Q)):
+                        kk = min(5, at)
+                        exp = np.sort(S[qi])[::-1][:kk]
+                        np.testing.assert_allclose(D[qi][:kk], exp, rtol=1e-5, atol=1e-6)
+                        np.testing.assert_allclose(S[qi][I[qi][:kk]], exp, rtol=1e-5, atol=1e-6)
+                ix.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
