@@ -336,3 +336,29 @@ def test_distinct_indexes_from_distinct_threads(ssa):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_hip_path_reproduces_the_output_faiss_publishes_for_its_flat_tutorial(ssa, storage):
+    """The one external known answer in reach (tests/golden/faiss_tutorial_flat.json: what FAISS's documentation prints
+    for tutorial/python/1-Flat.py), through the C-ABI: 100000 x 65 augmented rows, the published ids bit for bit (K1,
+    d = 65 padded to 72), the published distances after the exact L2 <-> inner-product mapping.  fp16 storage rounds the
+    rows (and the augmented norm term), so there the ids are required for the sanity block only (distance 0 to itself)
+    and elsewhere at least three of four."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import faiss_tutorial as ft
+    xb, xq = ft.data()
+    for name, q, I_pub, D_pub in ft.blocks(xb, xq):
+        Xa, Qa, qn = ft.as_inner_product(xb, q)
+        index = ssa.IndexFlatIP(65, storage=storage)
+        index.add(Xa)
+        D, I = index.search(Qa, 4)
+        if storage == "f32":
+            np.testing.assert_array_equal(I, I_pub, err_msg=name)
+            if D_pub is not None:
+                np.testing.assert_allclose(qn[:, None] - 2.0 * D.astype(np.float64), D_pub, rtol=2e-5, atol=2e-5, err_msg=name)
+        else:
+            assert (I[:, 0] == I_pub[:, 0]).all(), name
+            assert min(len(set(a) & set(b)) for a, b in zip(I, I_pub)) >= 3, (name, I, I_pub)
+        index.close()

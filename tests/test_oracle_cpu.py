@@ -1,7 +1,10 @@
 """CPU tests of the oracle itself.  Parity is unpinned by the reference (no tests,
 fixtures or FAISS in reach: SURVEY.md 8c), so the oracle is pinned against (a) a
-float64 brute force on small cases, (b) its independent C restatement and (c) the
-golden vectors in tests/golden/ that tests/golden/make_golden.py generated."""
+float64 brute force on small cases, (b) its independent C restatement, (c) the
+golden vectors in tests/golden/ that tests/golden/make_golden.py generated and
+(d) the one external known answer in reach: the output FAISS's own documentation
+prints for its Flat tutorial (tests/golden/faiss_tutorial_flat.json), mapped exactly
+onto the inner-product search of this path."""
 import json
 from pathlib import Path
 
@@ -101,3 +104,21 @@ def test_golden_flat_vectors():
         D, I = flat_ip.search(X, Q, case["k"])
         ok, msg, _ = flat_ip.check_against(D, I, data[case["name"] + "_D"], data[case["name"] + "_I"], X, Q, 1e-5, 1e-5)
         assert ok, f"{case['name']}: {msg}"
+
+
+def test_oracle_reproduces_the_output_faiss_publishes_for_its_flat_tutorial():
+    """FAISS wiki 'Getting started' / tutorial/python/1-Flat.py: exact search over 100000 x 64 vectors (seed 1234),
+    k = 4, printed for the first five database vectors and the first / last five queries.  L2 there, inner product here:
+    ||x-q||^2 = ||q||^2 - 2 <[q,1],[x,-||x||^2/2]> turns one into the other exactly (tests/golden/faiss_tutorial.py), so
+    both oracles must return FAISS's published ids, in FAISS's order, and the published distances."""
+    import sys
+    sys.path.insert(0, str(GOLDEN))
+    import faiss_tutorial as ft
+    xb, xq = ft.data()
+    for name, q, I_pub, D_pub in ft.blocks(xb, xq):
+        Xa, Qa, qn = ft.as_inner_product(xb, q)
+        for impl in (flat_ip, c_oracle):
+            D, I = impl.search(Xa, Qa, 4)
+            np.testing.assert_array_equal(I, I_pub, err_msg=f"{name} {impl.__name__}")
+            if D_pub is not None:
+                np.testing.assert_allclose(qn[:, None] - 2.0 * D.astype(np.float64), D_pub, rtol=2e-5, atol=2e-5, err_msg=name)
