@@ -382,7 +382,8 @@ int ssmi_index_read(const char* path, int storage_dtype, int device, ssmi_index*
     int d; int64_t ntotal; bool trained;
     CHECK(read_header(f, &d, &ntotal, &trained));
     uint64_t nlist, nprobe;
-    if (!rd1(f, &nlist) || !rd1(f, &nprobe) || nlist < 1 || nlist > (1u << 24)) return fail("read_index: corrupt IVF header");
+    // nprobe above nlist is legal in a FAISS file (the search clamps it); one that does not fit an int is damage
+    if (!rd1(f, &nlist) || !rd1(f, &nprobe) || nlist < 1 || nlist > (1u << 24) || nprobe > 0x7fffffffull) return fail("read_index: corrupt IVF header");
     ssmi_index* h = nullptr;
     CHECK(ssmi_index_create_ivfflat(d, (int)nlist, storage_dtype, device, &h));
     struct Guard { ssmi_index* h; ~Guard() { if (h) ssmi_index_free(h); } } guard{h};

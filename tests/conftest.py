@@ -4,6 +4,10 @@ from pathlib import Path
 
 import pytest
 
+# the seeded sweeps draw from default_rng(base + seed + SALT): SSMI_FUZZ_SALT=<n> re-runs them on other cases (a soak run;
+# the committed suite runs with 0)
+SALT = 100000 * int(os.environ.get("SSMI_FUZZ_SALT", "0"))
+
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))

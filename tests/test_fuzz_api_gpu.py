@@ -5,6 +5,8 @@ every route (bit-identical D and I).  Companion of tests/test_fuzz_gpu.py, which
 import numpy as np
 import pytest
 
+from conftest import SALT
+
 from conftest import unit_rows
 from oracle import flat_ip
 
@@ -25,7 +27,7 @@ def test_shard_merge_sweep(ssa, seed):
     ssmi_topk_merge give exactly what one index over all rows gives (same kernels, same keys: bit-identical)."""
     import torch
     from semantic_search_amd.faiss_compat import topk_merge
-    rng = np.random.default_rng(3000 + seed)
+    rng = np.random.default_rng(3000 + seed + SALT)
     d = int(rng.choice([64, 256, 1024, 4096]))
     n = int(rng.choice([5, 300, 2000, 5000]))
     world = int(rng.choice([1, 2, 3, 8]))
@@ -63,7 +65,7 @@ def test_shard_merge_sweep(ssa, seed):
 def test_file_roundtrip_sweep(ssa, tmp_path, seed):
     """write_index -> read_index gives an index that answers bit-identically, for Flat and IVF, both storages, after
     incremental checkpoints (appended Flat rows, IVF journal records) as well as after a full write."""
-    rng = np.random.default_rng(4000 + seed)
+    rng = np.random.default_rng(4000 + seed + SALT)
     kind = str(rng.choice(["flat", "ivf"]))
     d = int(rng.choice([24, 72, 256, 1024]))
     storage = str(rng.choice(["f32", "f16"]))
@@ -105,7 +107,7 @@ def test_floor_and_device_io_sweep(ssa, seed):
     """min_score cuts a row exactly where the unfloored row drops below it, on every path; device tensors in and out
     (fresh or caller-provided outputs) give the bits the numpy route gives."""
     import torch
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(5000 + seed + SALT)
     kind = str(rng.choice(["flat", "ivf"]))
     d = int(rng.choice([64, 100, 512, 4096]))
     storage = str(rng.choice(["f32", "f16"]))
@@ -144,7 +146,7 @@ def test_floor_and_device_io_sweep(ssa, seed):
 def test_readback_sweep(ssa, seed):
     """reconstruct / reconstruct_n / reconstruct_batch(_device) / score_ids on Flat and IVF (with a direct map) give the
     stored rows (fp16-rounded under f16 storage) and their inner products; ids out of range are an error, not a read."""
-    rng = np.random.default_rng(7000 + seed)
+    rng = np.random.default_rng(7000 + seed + SALT)
     kind = str(rng.choice(["flat", "ivf"]))
     d = int(rng.choice([8, 100, 256, 4096]))
     storage = str(rng.choice(["f32", "f16"]))
@@ -187,7 +189,7 @@ def test_threads_with_their_own_indexes_streams_and_lifetimes(ssa):
 
     def worker(t):
         try:
-            rng = np.random.default_rng(100 + t)
+            rng = np.random.default_rng(100 + t + SALT)
             stream = torch.cuda.Stream() if t % 2 else None
             for rep in range(6):
                 d = int(rng.choice([64, 256, 1024]))

@@ -8,7 +8,7 @@ import struct
 import numpy as np
 import pytest
 
-from conftest import unit_rows
+from conftest import SALT, unit_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -37,7 +37,7 @@ def _usable(ssa, index, d):
 
 @pytest.mark.parametrize("seed", range(8))
 def test_damaged_files_raise_or_load(ssa, tmp_path, seed):
-    rng = np.random.default_rng(6000 + seed)
+    rng = np.random.default_rng(6000 + seed + SALT)
     d, X, pf, pi = _make_files(ssa, tmp_path)
     outcomes = {"raised": 0, "loaded": 0}
     for trial in range(40):
@@ -98,3 +98,30 @@ def test_torn_and_foreign_journals_leave_the_base_index(ssa, tmp_path):
     ix2.set_centroids(unit_rows(9, d, 6)); ix2.add(X[:50]); ssa.write_index(ix2, other)
     shutil.copy(jp, str(other) + ".journal")
     assert ssa.read_index(other).ntotal == 50
+
+
+def test_nprobe_field_of_an_ivf_file(ssa, tmp_path):
+    """IwFl header: fourcc, d:i32, ntotal:i64, two i64, is_trained:u8, metric:i32 = 37 bytes, then nlist:u64, nprobe:u64.
+    Found by the salted sweep (SSMI_FUZZ_SALT=3, seed 4): a value whose low 32 bits are zero loaded as nprobe 0 and the
+    first search failed in the coarse step.  Above nlist is legal (FAISS clamps at search time), zero reads as 1, a value
+    beyond an int is damage."""
+    d, X, pf, pi = _make_files(ssa, tmp_path)
+    (tmp_path / "ivf.faiss.journal").unlink()
+    raw = bytearray(pi.read_bytes())
+    assert struct.unpack_from("<Q", raw, 37)[0] == 9
+    Q = unit_rows(3, d, 1)
+    exact = np.argsort(-(Q.astype(np.float64) @ X[:600].astype(np.float64).T), axis=1, kind="stable")[:, :5]
+    for value, outcome in [(0, 1), (9 + 5, 14), (1 << 40, None), ((1 << 64) - 1, None), (1 << 31, None), ((1 << 31) - 1, (1 << 31) - 1)]:
+        v = tmp_path / f"np{value}.faiss"
+        struct.pack_into("<Q", raw, 45, value)
+        v.write_bytes(bytes(raw))
+        if outcome is None:
+            with pytest.raises(RuntimeError, match="corrupt IVF header"):
+                ssa.read_index(v)
+            continue
+        ix = ssa.read_index(v)
+        assert ix.nprobe == outcome and ix.ntotal == 600
+        D, I = ix.search(Q, 5)
+        if outcome >= 9:      # every list probed: the exact result
+            np.testing.assert_array_equal(I, exact)
+        ix.close()

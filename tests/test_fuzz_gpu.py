@@ -10,7 +10,7 @@ rows against the fp32 oracle at the north star's 1e-3.  Seeds are fixed: a failu
 import numpy as np
 import pytest
 
-from conftest import unit_rows
+from conftest import SALT, unit_rows
 from oracle import flat_ip, ivf_flat
 
 pytestmark = pytest.mark.gpu
@@ -40,7 +40,7 @@ def add_in_pieces(index, X, rng):
 
 @pytest.mark.parametrize("seed", range(120))
 def test_flat_sweep(ssa, monkeypatch, seed):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + seed + SALT)
     d = int(rng.choice(DIMS))
     n = int(rng.choice(ROWS))
     nq = int(rng.choice(BATCHES))
@@ -80,7 +80,7 @@ def test_flat_sweep(ssa, monkeypatch, seed):
 
 @pytest.mark.parametrize("seed", range(60))
 def test_ivf_sweep(ssa, monkeypatch, seed):
-    rng = np.random.default_rng(2000 + seed)
+    rng = np.random.default_rng(2000 + seed + SALT)
     d = int(rng.choice([24, 64, 100, 256, 512, 1024, 2048, 4096]))
     nlist = int(rng.choice([1, 3, 16, 40, 64, 200]))
     n = int(rng.choice([nlist, 257, 1000, 3071, 6000]))
@@ -103,7 +103,10 @@ def test_ivf_sweep(ssa, monkeypatch, seed):
     index.set_centroids(C)
     add_in_pieces(index, X, rng)
     labels = index.assignments()
-    assert ivf_flat.assignment_is_valid(X, C, labels, rtol=2e-3), case
+    # pieces of 9 vectors and more are assigned on fp16 centroids and fp16-rounded vectors: the absolute floor of the Flat
+    # sweep above (a score near zero has no relative tolerance to speak of; found with SSMI_FUZZ_SALT=7, seed 21: two
+    # centroids 1.3e-5 apart at a score of -0.0016)
+    assert ivf_flat.assignment_is_valid(X, C, labels, rtol=2e-3, atol=6 * 2.0 ** -11 * np.sqrt(2.0 / d)), case
     np.testing.assert_array_equal(index.list_sizes(), np.bincount(labels, minlength=nlist))
     index.nprobe = nprobe
     D, I = index.search(Q, k)
@@ -164,7 +167,7 @@ def test_ivf_grow_and_search_walk(ssa, monkeypatch, seed):
     batch sizes, k and nprobe: per-query scans, list-major scans and (fp16 rows, or the fp16 shadow of fp32 lists) the
     matrix-core scan all read the same page tables, which every add extends; after each step the result must match the
     oracle run on the index's own assignment of everything added so far."""
-    rng = np.random.default_rng(2500 + seed)
+    rng = np.random.default_rng(2500 + seed + SALT)
     d = int(rng.choice([64, 512, 1024, 4096]))
     nlist = int(rng.choice([4, 16, 50]))
     storage = str(rng.choice(["f32", "f16"]))

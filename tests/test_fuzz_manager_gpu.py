@@ -7,6 +7,8 @@ exact, so one model serves both types; the buffering phase of an untrained IVF i
 import numpy as np
 import pytest
 
+from conftest import SALT
+
 from conftest import unit_rows
 
 pytestmark = pytest.mark.gpu
@@ -56,7 +58,7 @@ def check_search(si, model, q, k, min_score=0.0):
 @pytest.mark.parametrize("seed", range(32))
 def test_semantic_index_random_walk(ssa, tmp_path, seed):
     from semantic_search_amd.index_manager import SemanticIndex
-    rng = np.random.default_rng(8000 + seed)
+    rng = np.random.default_rng(8000 + seed + SALT)
     d = int(rng.choice([32, 96, 256]))
     storage = str(rng.choice(["f32", "f16"]))
     itype = str(rng.choice(["flat", "ivf_flat"]))

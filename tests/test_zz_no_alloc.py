@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import unit_rows
+from conftest import SALT, unit_rows
 from oracle import flat_ip
 
 pytestmark = pytest.mark.gpu
@@ -124,7 +124,7 @@ def test_static_search_sweep(ssa, monkeypatch, seed):
     bit for bit, call after call on the shared array; a request beyond the array is refused with a message."""
     import torch
     monkeypatch.setenv("SSMI_MFMA_MIN_B", "1000000")
-    rng = np.random.default_rng(9000 + seed)
+    rng = np.random.default_rng(9000 + seed + SALT)
     d = int(rng.choice([8, 64, 256, 1000, 1024, 4096]))
     storage = str(rng.choice(["f32", "f16"]))
     n = int(rng.choice([1, 70, 257, 3000, 20000]))
