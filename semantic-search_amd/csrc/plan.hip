@@ -45,6 +45,7 @@ bool plan_flat_scan(int dtype, int ld, long long nrows, int nq, int k, int num_c
         p->nch = 0;
         const size_t qbytes = (size_t)bt * ldq * 4;
         p->threads = qbytes > 80 * 1024 ? 1024 : (qbytes > 40 * 1024 ? 512 : 256);
+        if (const char* e = getenv("SSMI_SCAN_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) p->threads = v; }
         const size_t mbytes = (size_t)(p->threads / 64) * kp * sizeof(skey_t);
         p->lds = qbytes > mbytes ? qbytes : mbytes;
         blocks_per_cu = (int)((160 * 1024) / (p->lds + 512));
@@ -52,6 +53,16 @@ bool plan_flat_scan(int dtype, int ld, long long nrows, int nq, int k, int num_c
         if (blocks_per_cu > wave_cap) blocks_per_cu = wave_cap;
         if (blocks_per_cu > 4) blocks_per_cu = 4;
         if (blocks_per_cu < 1) blocks_per_cu = 1;
+        // long rows, 2-4 queries: one block of 8 waves per CU (8 rows of 8-16 KiB in flight) instead of 16 waves. Measured at
+        // 1M x 4096 (tools/time_env_ab.py, SSMI_SCAN_THREADS x SSMI_SCAN_BPC): fp32 rows 2 queries 2.54 -> 2.35 ms, 3-4 queries
+        // 2.43 -> 2.35 ms (0.87 of 8 TB/s, what one query reaches); fp16 rows 2 queries 1.335 -> 1.177 ms; fp16 rows with 3-4
+        // queries (1.29 ms) and 5-8 queries on fp32 rows (2.52 ms) lose with fewer waves and keep 16
+        const size_t row_bytes = (size_t)ld * (dtype == 0 ? 4 : 2);
+        if (!getenv("SSMI_SCAN_THREADS") && row_bytes >= 8192 && (bt == 2 || (bt == 4 && dtype == 0)) && mbytes <= 64 * 1024) {
+            p->threads = 512;
+            p->lds = qbytes > (size_t)8 * kp * sizeof(skey_t) ? qbytes : (size_t)8 * kp * sizeof(skey_t);
+            blocks_per_cu = 1;
+        }
     }
     const char* env_bpc = getenv("SSMI_SCAN_BPC");
     if (env_bpc) { int v = atoi(env_bpc); if (v >= 1 && v <= 16) blocks_per_cu = v; }
