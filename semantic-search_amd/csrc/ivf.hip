@@ -987,18 +987,26 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
     const int qthreads = qreg_threads(R.dtype, row_kib, r, qrows);
     int qbpc = 1;  // blocks per CU for one query
     if (const char* e = getenv("SSMI_IVF_BPC")) qbpc = atoi(e);
-    const int gx = qreg ? (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)h->num_cu * qbpc, ((int64_t)h->num_cu * 2 * qbpc + nq - 1) / nq))
+    // several queries in one launch share two rounds of blocks (2 x CUs); rounded DOWN per query, so that the launch never
+    // spills into a third, nearly empty round (17 queries x 31 blocks = 527 ran 87 us per query against 77 us at 16 x 32)
+    const int gx = qreg ? (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)h->num_cu * qbpc, ((int64_t)h->num_cu * 2 * qbpc) / nq))
                         : (int)std::max<int64_t>(1, std::min<int64_t>(1024, ((int64_t)h->num_cu * 6 + nq - 1) / nq));
     const int V = R.dtype == SSMI_F32 ? 4 : 8;
     const int ldq = (R.ld + 64 * V - 1) / (64 * V) * 64 * V;
     const size_t lds = qreg ? (size_t)(qthreads / 64) * 64 * r * sizeof(skey_t) + R.segs.size() * sizeof(void*)
                             : std::max((size_t)ldq * 4, (size_t)4 * 64 * r * sizeof(skey_t));
     hipEvent_t* ev = h->ev[h->n_searches % ssmi_index::kEvRing];
-    // batches whose probes revisit the lists (on average >= 2 probes per list) take the list-major scan
+    // batches whose probes revisit the lists (on average >= 2 probes per list) take the list-major scan; large indexes
+    // already from one probe per three lists: the per-query scan costs the probed bytes once per query, the list-major one
+    // the union of the probed lists plus a fixed part (probe-table inversion, work items; 0.8 ms at nlist 4096). Measured on
+    // configs[3] (tools/time_ivf_batch_sweep.py, SSMI_SWEEP_AB=1): 32 queries 2.38 vs 2.52 ms, 48: 3.88 vs 3.35, 96: 7.26 vs
+    // 5.15, 192: 14.3 vs 7.4 ms
     int lbt = 0, lthreads = 0;
     size_t llds = 0;
     const char* env_lm = getenv("SSMI_IVF_LISTMAJOR");  // tests: 0 = never, 1 = always (when it fits)
-    bool list_major = nq >= 16 && nq * (int64_t)nprobe >= 2 * (int64_t)h->nlist;
+    const double per_query_bytes = (double)nq * nprobe / h->nlist * (double)R.nrows * R.ld * (R.dtype == SSMI_F32 ? 4 : 2);
+    bool list_major = nq >= 16 && (nq * (int64_t)nprobe >= 2 * (int64_t)h->nlist ||
+                                   (3 * nq * (int64_t)nprobe >= (int64_t)h->nlist && per_query_bytes >= 8e9));
     if (env_lm) list_major = env_lm[0] == '1';
     list_major = list_major && plan_ivf_list_scan(R.dtype, R.ld, k, &lbt, &lthreads, &llds);
     const char* env_lmm = getenv("SSMI_IVF_LIST_MFMA");  // 0: keep the register-FMA form
