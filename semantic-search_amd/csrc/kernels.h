@@ -29,6 +29,7 @@ struct MfmaPlan {
     int gtop_m;   // scores every slice publishes per query for the cross-slice threshold bound (0: none)
     bool narrow;  // <= 128 queries: the HBM-bound 128-query-tile stream (mfma_n128.hip)
     long long rows_per_slice;
+    int q_pitch;  // halves per row of the fp16 query workspace (ld, or ld + 64 for the 256-query kernel)
     size_t qh_bytes, cand_bytes, lds;
     const char* kernel;  // which contraction kernel launch_flat_mfma will run
 };

@@ -33,20 +33,30 @@
 
 namespace ssmi {
 
+// pitch == ld: plain rows.  pitch == ld + 64 (the 256-query kernel, mfma_pp.hip): a row is [32 halves of zeros][ld
+// values][the first 32 values again], so that the 128-byte pieces of the query stream that start at an ODD 32-deep
+// phase are whole cache lines and the piece behind the last phase holds the first phase of the next row tile.
 __global__ void cvt_queries_f16_kernel(const float* __restrict__ q, int nq, int ld, _Float16* __restrict__ out,
-                                       unsigned* __restrict__ gthr, unsigned* __restrict__ gtop, int gtop_words) {
+                                       unsigned* __restrict__ gthr, unsigned* __restrict__ gtop, int gtop_words, int pitch) {
     const int i = blockIdx.x;  // padded row
     if (gthr && threadIdx.x == 0) gthr[i] = 0;
     if (gtop)
         for (int e = threadIdx.x; e < gtop_words; e += blockDim.x) gtop[(size_t)i * gtop_words + e] = 0;
+    const int off = (pitch - ld) / 2;
     for (int e = threadIdx.x; e < ld; e += blockDim.x)
-        out[(size_t)i * ld + e] = (i < nq) ? (_Float16)q[(size_t)i * ld + e] : (_Float16)0.f;
+        out[(size_t)i * pitch + off + e] = (i < nq) ? (_Float16)q[(size_t)i * ld + e] : (_Float16)0.f;
+    if (off) {
+        for (int e = threadIdx.x; e < off; e += blockDim.x) {
+            out[(size_t)i * pitch + e] = (_Float16)0.f;
+            out[(size_t)i * pitch + off + ld + e] = (i < nq) ? (_Float16)q[(size_t)i * ld + e] : (_Float16)0.f;
+        }
+    }
 }
 
 // (nq, ld) fp32 -> (rows_out, ld) fp16, zero rows beyond nq
 hipError_t launch_cvt_queries_f16(const float* q, int nq, int rows_out, int ld, void* out, hipStream_t s) {
     hipLaunchKernelGGL(cvt_queries_f16_kernel, dim3(rows_out), dim3(256), 0, s, q, nq, ld, (_Float16*)out, (unsigned*)nullptr,
-                       (unsigned*)nullptr, 0);
+                       (unsigned*)nullptr, 0, ld);
     return hipGetLastError();
 }
 
@@ -65,12 +75,13 @@ bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_c
     int m = (int)((std::max<long long>(64, (long long)k * 5 / 4) + p->nslices - 1) / p->nslices);
     m = std::max(1, std::min(std::min(m, 8), k));
     p->gtop_m = (p->nslices > 1 && (long long)p->nslices * m >= k) ? m : 0;
-    // fp16 queries + shared thresholds + published tops
-    p->qh_bytes = (size_t)p->nqt * TN * ld * 2 + (size_t)p->nqt * TN * sizeof(unsigned) +
-                  (size_t)p->nqt * TN * p->nslices * p->gtop_m * sizeof(unsigned);
-    p->cand_bytes = (size_t)p->grid * TN * CAND_CAP * sizeof(skey_t);
     const char* env_n = getenv("SSMI_MFMA_NARROW");
     p->narrow = nq <= N128_TN && !(env_n && env_n[0] == '0');
+    // fp16 queries (the 256-query kernel takes rows of ld + 64: see cvt_queries_f16_kernel) + shared thresholds + published tops
+    p->q_pitch = p->narrow ? ld : ld + 64;
+    p->qh_bytes = (size_t)p->nqt * TN * p->q_pitch * 2 + (size_t)p->nqt * TN * sizeof(unsigned) +
+                  (size_t)p->nqt * TN * p->nslices * p->gtop_m * sizeof(unsigned);
+    p->cand_bytes = (size_t)p->grid * TN * CAND_CAP * sizeof(skey_t);
     const char* env_r = getenv("SSMI_MFMA_R128");
     p->kernel = !p->narrow ? "flat_mfma_pp_kernel"
                 : (mfma_r128_supported(ld, k) && !(env_r && env_r[0] == '0')) ? "flat_mfma_r128_kernel" : "flat_mfma_n128_kernel";
@@ -80,7 +91,7 @@ bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_c
 
 hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, const MfmaPlan& p, void* qh, void* cand,
                             skey_t* partial, hipStream_t s, unsigned min_ord) {
-    unsigned* gthr = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(qh) + (size_t)p.nqt * TN * X.ld * 2);
+    unsigned* gthr = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(qh) + (size_t)p.nqt * TN * p.q_pitch * 2);
     const char* env_t = getenv("SSMI_MFMA_SHARE_THR");
     const bool share_thr = !(env_t && env_t[0] == '0');
     const char* env_g = getenv("SSMI_MFMA_SHARE_TOPS");
@@ -88,11 +99,11 @@ hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, con
     const bool share_tops = share_thr && p.gtop_m > 0 && k > 1 && !(p.narrow && nq < 32 && k <= 16) && !(env_g && env_g[0] == '0');
     unsigned* gtop = gthr + (size_t)p.nqt * TN;
     hipLaunchKernelGGL(cvt_queries_f16_kernel, dim3(p.nqt * TN), dim3(256), 0, s, Q, nq, X.ld, (_Float16*)qh, gthr,
-                       share_tops ? gtop : (unsigned*)nullptr, p.nslices * p.gtop_m);
+                       share_tops ? gtop : (unsigned*)nullptr, p.nslices * p.gtop_m, p.q_pitch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     MfmaParams P = {};
-    P.X = X; P.Qh = (const _Float16*)qh; P.nq = nq; P.k = k; P.nqt = p.nqt; P.nslices = p.nslices;
+    P.X = X; P.Qh = (const _Float16*)qh; P.q_pitch = p.q_pitch; P.nq = nq; P.k = k; P.nqt = p.nqt; P.nslices = p.nslices;
     P.rows_per_slice = p.rows_per_slice; P.partial = partial; P.cand = (skey_t*)cand;
     P.gthr = (share_thr && p.nslices > 1) ? gthr : nullptr;
     P.gtop = share_tops ? gtop : nullptr;

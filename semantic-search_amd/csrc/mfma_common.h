@@ -14,7 +14,8 @@ static constexpr int CAND_CAP = 512, CAND_TRIG = 256;
 
 struct MfmaParams {
     RowView X;                 // fp16 rows, ld % 64 == 0
-    const _Float16* Qh;        // [nqt*256][ld] fp16, zero rows beyond nq
+    const _Float16* Qh;        // [nqt*256][q_pitch] fp16, zero rows beyond nq
+    int q_pitch;               // ld (128-query kernels) or ld + 64 (256-query kernel: see cvt_queries_f16_kernel)
     int nq, k, nqt, nslices;
     long long rows_per_slice;  // multiple of 256
     skey_t* partial;           // [nq][nslices][k]

@@ -3,31 +3,48 @@
 // fed continuously.
 //
 // Workgroup = 8 waves = two groups of four (group g = waves 4g..4g+3, one wave
-// of each group per SIMD).  The K dimension is walked in PHASES of 32: phase p
-// needs one 16 KiB slab of X (256 rows x 64 B) and one of Q.  Slabs live in a
-// ring of four (128 KiB LDS) and are filled by LDS-DMA three phases ahead.
+// of each group per SIMD).  The K dimension is walked in PHASES of 32 (one LOAD and
+// one MFMA segment each); the operands arrive in DOUBLE slabs of 64 (256 rows x 128 B
+// = 32 KiB), so that every LDS-DMA instruction reads 8 rows x 128 B = 8 whole cache
+// lines instead of 16 half lines that the next phase fetched again.  The row slabs
+// (X) cover phases (2D, 2D+1) and are issued in even phases, the query slabs (Q) cover
+// phases (2E+1, 2E+2) and are issued in odd phases: every LOAD segment issues four
+// pieces per wave, as before.  (All eight of a pair in the even phase measured 1 %
+// SLOWER than half-line pieces: a piece costs 100+ cycles of issue in a LOAD segment,
+// and a segment of eight outlasts the partner's MFMAs.)  Query rows are stored with 64
+// bytes in front and the first 64 bytes repeated behind (cvt_queries_f16_kernel), so
+// the odd-phase pieces are whole lines too and the piece behind the last phase holds
+// phase 0 of the next row tile.  Ring: two X slabs + two Q slabs = 128 KiB LDS.
 //
-//   group body, phase p:   ds_read fragments of slab p            (LOAD segment)
-//                          s_waitcnt vmcnt(4)   -> own DMA of slab p+1 landed
+//   group body, phase p:   issue the 4 pieces of X slab p/2+1 (p even) or Q slab (p+1)/2 (p odd)
+//                          ds_read fragments of phase p                       (LOAD segment)
+//                          group 1: s_waitcnt vmcnt(4) -> own pieces of the PREVIOUS phase landed
 //                          s_barrier
-//                          s_waitcnt lgkmcnt(0)
-//                          issue DMA of slab p+3, 32 MFMAs          (MFMA segment)
+//                          s_waitcnt lgkmcnt(0), 32 MFMAs                     (MFMA segment)
+//                          group 0: s_waitcnt vmcnt(4)
 //                          s_barrier
 //
 // Group 1 runs one barrier behind group 0, so between any two barrier events one
 // group is in its MFMA segment while the other reads LDS: the matrix pipe only
-// idles when a LOAD segment outlasts 32 MFMAs.  Hazards (all by construction):
-//   RAW  slab p+1 is read one phase after every wave's vmcnt wait + a barrier
-//   WAR  slab p+3 overwrites slab p-1, whose last ds_reads were retired by an
-//        lgkmcnt(0) at least one barrier event earlier
+// idles when a LOAD segment outlasts 32 MFMAs.  Barrier events of group 0: LOAD(p)
+// ends with event 2p, MFMA(p) with 2p+1; group 1 is one event later.  Hazards (all
+// by construction): a slab issued in LOAD(p) is first read in LOAD(p+2) and
+// overwrites one last read in LOAD(p-1).
+//   RAW  group 0 enters LOAD(p+2) after event 2p+3; every wave has waited for its own
+//        pieces before that event (group 0 behind the MFMAs of phase p+1, group 1 at
+//        the end of its LOAD(p+1))
+//   WAR  the issue follows event 2p-1 (group 0) or 2p (group 1); the ds_reads of
+//        LOAD(p-1) were retired by an lgkmcnt(0) before event 2p-2 (group 0) / 2p-1
+//        (group 1)
 // The ring runs on across row tiles: when the next row tile is whole and lies in the
-// same storage segment, the last three phases of a tile fetch slabs 0..2 of the next
-// one (its rows are one tile stride further on), so the epilogue is not followed by a
-// pipeline fill.  Otherwise (segment boundary, last tile, phases not a multiple of the
-// ring) the fill is issued after the K loop, before the epilogue.
-// Slab image: 64-byte rows, 16-byte chunk c of row r stored at chunk
-// c ^ ((-(r >> 2)) & 3) (applied to the DMA SOURCE address and to the reads),
-// which makes every ds_read_b128 fragment read bank-conflict free.
+// same storage segment, the last even phase fetches X slab 0 of the next tile (its
+// rows are one tile stride further on) and the last odd phase its Q slab 0; its phase
+// 0 reads the query piece behind this tile's last phase.  Otherwise (segment boundary,
+// last tile, phases not a multiple of four) the fill is issued after the K loop,
+// before the epilogue.
+// Slab image: 128-byte rows, 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7)
+// (applied to the DMA SOURCE address and to the reads): the 16 lanes of one pass of a
+// ds_read_b128 then cover all 64 banks once.
 #include "mfma_common.h"
 #ifdef SSMI_STAMP
 #include <cstdio>
@@ -41,9 +58,10 @@
 
 namespace ssmi {
 
-static constexpr int SLAB = 256 * 64;          // one operand slab: 16 KiB
-static constexpr int PHASE_LDS = 2 * SLAB;     // X slab + Q slab
-static constexpr int RING = 4;
+static constexpr int SLAB = 256 * 128;         // one operand's double slab (two phases): 32 KiB
+static constexpr int PHASE_LDS = 2 * SLAB;     // one X slab + one Q slab
+static constexpr int RING = 2;                 // double slabs per operand in the ring: X at [0, 64 KiB), Q at [64, 128 KiB)
+static constexpr int QRING = RING * SLAB;      // offset of the Q slabs
 
 // ARGMAX (k == 1: IVF centroid assignment, K5): no threshold, candidate buffers or folds at all - every lane keeps
 // the best (score, row) of each of its four query columns across the row tiles of the slice, the four lanes and two
@@ -87,54 +105,56 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
     const int np = ld / 32;  // phases per row tile
     const long long seg_mask = (1ll << P.X.seg_shift) - 1;
 
-    // DMA slots: slab = 16 wave-instructions of 1 KiB (16 rows x 64 B); wave w owns
-    // instructions 2w, 2w+1 of the X slab and of the Q slab.  Lane i fills row i>>2,
-    // physical chunk i&3, i.e. logical chunk (i&3) ^ f(row).
-    int slot_row[2], slot_coff[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (wave * 2 + j) * 16 + (lane >> 2);
-        slot_row[j] = row;
-        slot_coff[j] = (((lane & 3) ^ ((-(row >> 2)) & 3))) * 16;
-    }
-    const unsigned char* qsrc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-        qsrc[j] = reinterpret_cast<const unsigned char*>(P.Qh) + (size_t)(q0 + slot_row[j]) * ld * 2 + slot_coff[j];
+    // DMA pieces: a double slab = 32 wave-instructions of 1 KiB (8 rows x 128 B); wave w owns pieces 4w..4w+3 of an X slab
+    // and of a Q slab.  In piece j lane i fills row (4w+j)*8 + (i>>3), physical chunk i&7, i.e. logical chunk
+    // (i&7) ^ ((row>>1)&7) = (i&7) ^ (i>>4) ^ 4(j&1): one lane offset, flipped by 64 bytes in the odd pieces.
+    const int piece_row0 = wave * 32 + (lane >> 3);
+    const int piece_coff = ((lane & 7) ^ (lane >> 4)) * 16;
+    const unsigned char* qbase = reinterpret_cast<const unsigned char*>(P.Qh) + (size_t)(q0 + piece_row0) * P.q_pitch * 2;
+    const unsigned q_step = 16u * (unsigned)P.q_pitch;   // from one piece of the wave to the next
 
-    // fragment read offsets inside a slab
+    // fragment read offsets inside a double slab, first and second phase of the pair
     const int frow = lane & 15, fq = lane >> 4;
-    const int fch = (fq ^ ((-(frow >> 2)) & 3)) * 16;
-    const int a_off = (wm * 128 + frow) * 64 + fch;
-    const int b_off = SLAB + (wn * 64 + frow) * 64 + fch;
+    const int fsw = (frow >> 1) & 7;
+    const int fch0 = (fq ^ fsw) * 16, fch1 = ((4 + fq) ^ fsw) * 16;
+    const int a_row = (wm * 128 + frow) * 128;
+    const int b_row = QRING + (wn * 64 + frow) * 128;
 
-    const unsigned char* asrc[2];
+    const unsigned char* asrc[4];
     auto set_rows = [&](long long row0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            long long r = row0 + slot_row[j];
+        for (int j = 0; j < 4; ++j) {
+            long long r = row0 + piece_row0 + 8 * j;
             if (r >= r_end) r = r_end - 1;
             asrc[j] = reinterpret_cast<const unsigned char*>(P.X.segs[r >> P.X.seg_shift]) +
-                      (size_t)(r & seg_mask) * (size_t)ld * 2 + slot_coff[j];
+                      (size_t)(r & seg_mask) * (size_t)ld * 2 + (piece_coff ^ ((j & 1) << 6));
         }
     };
-    // DMA of phase PH's slabs (PH = 0, 1, 2: the pipeline fill of a row tile) into ring slot PH; the K
-    // offset rides in the instruction's immediate field, so the fill needs no extra address registers
-#define ISSUE_FILL(PH)                                                                       \
+    // the wave's four pieces of an X slab (K offset KOFF bytes into the rows, TOFF more: the next tile) / of a Q slab
+    // (OFF bytes into the stored query rows) into ring slot SL
+#define ISSUE_X(SL, KOFF, TOFF)                                                              \
     {                                                                                        \
-        unsigned char* dst_ = smem + (PH) * PHASE_LDS + (wave * 2) * 1024;                   \
-        GLDS16O(asrc[0], dst_, (PH) * 64);                                                   \
-        GLDS16O(asrc[1], dst_ + 1024, (PH) * 64);                                            \
-        GLDS16O(qsrc[0], dst_ + SLAB, (PH) * 64);                                            \
-        GLDS16O(qsrc[1], dst_ + SLAB + 1024, (PH) * 64);                                     \
+        unsigned char* dst_ = smem + (SL) * SLAB + (wave * 4) * 1024;                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) GLDS16(asrc[j_] + (TOFF) + (KOFF), dst_ + j_ * 1024);          \
+    }
+#define ISSUE_Q(SL, OFF)                                                                     \
+    {                                                                                        \
+        unsigned char* dst_ = smem + QRING + (SL) * SLAB + (wave * 4) * 1024;                \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                \
+            GLDS16(qbase + j_ * q_step + (piece_coff ^ ((j_ & 1) << 6)) + (OFF), dst_ + j_ * 1024);                       \
+    }
+    // pipeline fill of a row tile: X slab 0, the query piece in front of phase 0 (Q slot 0) and Q slab 0 (Q slot 1)
+#define ISSUE_FILL()                                                                         \
+    {                                                                                        \
+        ISSUE_X(0, 0u, 0u)                                                                   \
+        ISSUE_Q(0, 0u)                                                                       \
+        ISSUE_Q(1, 128u)                                                                     \
     }
 
     if (r_begin < r_end) {
         set_rows(r_begin);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ISSUE_FILL(0)
-        if (1 < np) ISSUE_FILL(1)
-        if (2 < np) ISSUE_FILL(2)
+        ISSUE_FILL()
     }
 
 #ifdef SSMI_STAMP
@@ -172,14 +192,14 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
     uint32_t best_r[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) { best_s[n] = -__builtin_inff(); best_r[n] = 0xFFFFFFFFu; }
-    const size_t tile_stride = (size_t)TM * (size_t)ld * 2;
+    const unsigned tile_stride = (unsigned)TM * (unsigned)ld * 2u;   // 512 ld bytes: fits 32 bits for any row length in reach
     for (long long row0 = r_begin; row0 < r_end; row0 += TM) {
         // The ring runs on ACROSS row tiles when the next tile is whole and lies in the same storage segment
         // (its rows are then tile_stride bytes further on, no segment lookup) and the tile's phases fill whole
         // turns of the ring: the last three phases fetch the next tile's slabs 0..2 instead of nothing, so the
         // fill's HBM round trip hides behind MFMAs and the epilogue instead of following it.
         const long long next0 = row0 + TM;
-        const bool cont = (np & (RING - 1)) == 0 && np >= RING && next0 + TM <= r_end &&
+        const bool cont = (np & 3) == 0 && np >= 4 && next0 + TM <= r_end &&
                           (row0 >> P.X.seg_shift) == ((next0 + TM - 1) >> P.X.seg_shift);
         f32x4_t acc[8][4];
 #pragma unroll
@@ -199,31 +219,34 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
         if (wm == 1) __builtin_amdgcn_s_setprio(1);  // static priority for the younger half, no per-segment flips
 #endif
         for (int p = 0; p < np; ++p) {
-            const unsigned char* slab = smem + (p & (RING - 1)) * PHASE_LDS;
+            const int h = p & 1;
+            const unsigned char* slab_x = smem + ((p >> 1) & 1) * SLAB;           // X slab p/2, half h
+            const unsigned char* slab_q = smem + (((p + 1) >> 1) & 1) * SLAB;     // Q slab (p-1)/2 (slot (p+1)/2 & 1), half 1-h
             // ---- LOAD segment (the partner group owns the matrix pipe meanwhile) ----
-            // DMA of slab p+3 into the ring slot of slab p-1: every ds_read of slab p-1 was retired by
-            // an lgkmcnt(0) that its wave executed BEFORE a barrier event this wave has already passed.
-            if (p + 3 < np || cont) {
-                unsigned char* dst = smem + ((p + 3) & (RING - 1)) * PHASE_LDS + (wave * 2) * 1024;
-                const bool here = p + 3 < np;
-                const size_t qoff = (size_t)(here ? p + 3 : p + 3 - np) * 64;
-                const size_t koff = here ? qoff : tile_stride + qoff;
-                GLDS16(asrc[0] + koff, dst);
-                GLDS16(asrc[1] + koff, dst + 1024);
-                GLDS16(qsrc[0] + qoff, dst + SLAB);
-                GLDS16(qsrc[1] + qoff, dst + SLAB + 1024);
+            // four pieces into the ring slot whose last ds_reads (previous phase) every wave retired by an lgkmcnt(0)
+            // BEFORE a barrier event this wave has already passed
+            const bool more = p + 2 < np;
+            const bool issue = more || cont;
+            if (issue) {
+                if (h == 0) {
+                    const int d1 = (p >> 1) + 1;
+                    ISSUE_X(more ? (d1 & 1) : 0, more ? (unsigned)d1 * 128u : 0u, more ? 0u : tile_stride)
+                } else {
+                    const int e1 = (p + 1) >> 1;   // Q slab e1 = phases p+2, p+3; behind the last phase: slab 0 of the next tile
+                    ISSUE_Q(more ? ((e1 + 1) & 1) : 1, more ? (unsigned)(e1 + 1) * 128u : 128u)
+                }
             }
             half8_t a[8], b[4];
+            const int ao = a_row + (h ? fch1 : fch0), bo = b_row + (h ? fch0 : fch1);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) a[m] = *reinterpret_cast<const half8_t*>(slab + a_off + m * 16 * 64);
+            for (int m = 0; m < 8; ++m) a[m] = *reinterpret_cast<const half8_t*>(slab_x + ao + m * 16 * 128);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const half8_t*>(slab + b_off + n * 16 * 64);
-            // own DMA of slab p+1 must have landed before this phase's first barrier; the four
-            // instructions just issued (slab p+3) and the four of slab p+2 may stay in flight
-            if (p + 3 < np || cont) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (p + 2 < np) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers: slab p may be recycled
+            for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const half8_t*>(slab_q + bo + n * 16 * 128);
+            // the pieces of the PREVIOUS phase are read from the next phase on.  Every wave's own must have landed before
+            // the barrier event that lets group 0 into that phase: group 1 waits here, group 0 behind its MFMAs (one
+            // event later in its own sequence, the same event of the workgroup); this phase's four may stay in flight
+            if (wm == 1) { if (issue) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             // ---- MFMA segment ----
@@ -239,6 +262,7 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
             __builtin_amdgcn_s_setprio(0);
 #endif
             __builtin_amdgcn_sched_barrier(0);
+            if (wm == 0) { if (issue) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             __builtin_amdgcn_s_barrier();
         }
 #if SSMI_PP_PRIO == 1
@@ -249,14 +273,12 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
 
         // start the next row tile's pipeline before the epilogue: every ring slot is free now
         if (cont) {
-            asrc[0] += tile_stride;
-            asrc[1] += tile_stride;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asrc[j] += tile_stride;
         } else if (next0 < r_end) {
             set_rows(next0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            ISSUE_FILL(0)
-            if (1 < np) ISSUE_FILL(1)
-            if (2 < np) ISSUE_FILL(2)
+            ISSUE_FILL()
         }
 
         STAMP(2)
