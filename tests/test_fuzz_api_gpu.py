@@ -5,9 +5,7 @@ every route (bit-identical D and I).  Companion of tests/test_fuzz_gpu.py, which
 import numpy as np
 import pytest
 
-from conftest import SALT
-
-from conftest import unit_rows
+from conftest import SALT, unit_rows
 from oracle import flat_ip
 
 pytestmark = pytest.mark.gpu

@@ -7,9 +7,7 @@ exact, so one model serves both types; the buffering phase of an untrained IVF i
 import numpy as np
 import pytest
 
-from conftest import SALT
-
-from conftest import unit_rows
+from conftest import SALT, unit_rows
 
 pytestmark = pytest.mark.gpu
 
