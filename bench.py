@@ -16,6 +16,8 @@ import argparse
 import copy
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -55,6 +57,52 @@ def parse():
     ap.add_argument("--ivf-data", default="clustered", choices=["clustered", "iid"],
                     help="clustered: unit rows around 16384 random centres (sigma 0.6); iid: unit gaussian rows")
     return ap.parse_args()
+
+
+# --------------------------------------------------------------------------------------------- launch
+def launch_command(gpus, argv, port):
+    """The command the contract names for N > 1: one rank per GPU under torch.distributed.run, same arguments."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def world_mismatch(gpus, env):
+    """A launcher started W ranks but the command line says --gpus N != W: refuse rather than report n_gpus = W
+    under a command that asked for N.  The one-rank rehearsal (SSMI_BENCH_FORCE_DIST=1, --gpus 1) passes."""
+    ws = env.get("WORLD_SIZE")
+    if ws is None or int(ws) == gpus:
+        return None
+    return "bench.py: --gpus %d but WORLD_SIZE=%s: start it as `python bench.py --gpus %d` or under torch.distributed.run with --nproc-per-node %d" % (
+        gpus, ws, gpus, gpus)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def relay_ranks(gpus, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (this parent has made no
+    GPU call, and it never replaces itself), pass the child's JSON line and return code on."""
+    cmd = launch_command(gpus, argv, free_port())
+    print("[bench] --gpus %d without WORLD_SIZE: starting %s" % (gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        try:
+            if "metric" in json.loads(ln):
+                line = ln
+        except Exception:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif p.returncode == 0:
+        print("[bench] the ranks printed no JSON line", file=sys.stderr)
+        return 1
+    return p.returncode
 
 
 # --------------------------------------------------------------------------------------------- helpers
@@ -121,6 +169,17 @@ class Dist:
         t = torch.tensor([float(v)], dtype=torch.float64, device=self.dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    def devices(self):
+        """What each rank runs on, gathered over the process group: the bench line names the GPUs it used."""
+        p = torch.cuda.get_device_properties(self.dev)
+        mine = {"rank": self.rank, "device": "cuda:%d" % self.local_rank, "name": p.name,
+                "pci_bus_id": getattr(p, "pci_bus_id", None), "hbm_gib": round(p.total_memory / 2**30, 1)}
+        if not self.on:
+            return [mine]
+        out = [None] * self.world
+        dist.all_gather_object(out, mine)
+        return out
 
     def close(self):
         if self.on:
@@ -423,6 +482,7 @@ def run_ivf(args, D, emit=True, with_cpu=True):
     Df, If = (flat_s.search(Q, k) if sharded else flat.search(Q, k))
     torch.cuda.synchronize()
     recall = recall_at(Ii.cpu().numpy(), If.cpu().numpy(), k)
+    ranks = {"world": dist.get_world_size() if D.on else 1, "backend": dist.get_backend() if D.on else None, "devices": D.devices()}
     frac = algo_bytes / (scan_ms_sample * 1e-3) / 1e9 / HBM_PEAK_GBS
     line = {
         "metric": "queries/sec at k=%d, %d-d (IVF%d nprobe=%d, batch 1)" % (k, d, nlist, nprobe),
@@ -439,7 +499,7 @@ def run_ivf(args, D, emit=True, with_cpu=True):
                      "algorithmic_bytes_note": "mean rows of the probed lists held by rank 0 over 32 sample queries (%d; nprobe*N/nlist/world = %d) x d x 2 B, "
                                                "over the mean hipEvent time of those launches" % (int(probed_rows), int(nprobe * n / nlist / world)),
                      "kernel": scan_kernel, "kernel_avg_ms": scan_ms_sample},
-        "extra": {"train_s": t_train, "add_s": t_add, "add_vectors_per_s": n / t_add,
+        "extra": {"ranks": ranks, "train_s": t_train, "add_s": t_add, "add_vectors_per_s": n / t_add,
                   "list_sizes_rank0": {"min": int(ls.min()), "median": float(np.median(ls)), "max": int(ls.max())},
                   **small, "batch_1000_qps": 1000 / t_b, "batch_4096_qps": 4096 / t_b4, "batched_kernel": batched_kernel,
                   "batch_1000_hbm_frac_end_to_end": ub1000 / t_b / 1e9 / HBM_PEAK_GBS,
@@ -629,6 +689,11 @@ def side_c5_weak(args, D, g):
 # --------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
+    msg = world_mismatch(args.gpus, os.environ)
+    if msg:
+        raise SystemExit(msg)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relay_ranks(args.gpus, sys.argv[1:]))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (MI355X)")
     D = Dist()
@@ -658,7 +723,10 @@ def main():
         roof.pop("algorithmic_flops_per_launch", None)
     attach_committed_traffic(roof, args, world)
 
-    extra = {}
+    extra = {"ranks": {"world": dist.get_world_size() if D.on else 1,
+                       "backend": dist.get_backend() if D.on else None,   # "nccl" is RCCL on ROCm
+                       "devices": D.devices()}}
+    extra["rccl_world"] = extra["ranks"]["world"] if extra["ranks"]["backend"] == "nccl" else None
     line = None
     if rank == 0:
         line = {
