@@ -47,7 +47,9 @@ def parse():
     ap.add_argument("--no-ivf-extra", action="store_true", help="skip the IVF4096 / 10M-row side measurement (configs[3])")
     ap.add_argument("--no-c5", action="store_true", help="--gpus N>1: skip the configs[4] per-GPU-shape side measurement")
     ap.add_argument("--c5-rows", type=int, default=12_500_000, help="rows per GPU of the configs[4] side measurement")
-    ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000,
+                    help="rows of the database the CPU baseline scans (default: all 1M of configs[1] = 16.4 GB of host RAM; "
+                         "cut to 100k, labelled and extrapolated, when the host has less than 3x that free)")
     ap.add_argument("--workload", default="flat", choices=["flat", "ivf"],
                     help="flat = BASELINE configs[1] (the default bench line); ivf = configs[3] (IVF4096, nprobe 32; "
                          "with --gpus N the lists are sharded over the ranks and --n is the TOTAL row count)")
@@ -273,6 +275,12 @@ def cpu_baseline_flat(index, d, k, sample_rows, n_total, dev):
     plus a batch-100 numpy/BLAS leg (Q @ X.T + argpartition: configs[0]'s shape of work)."""
     from oracle import c_oracle
     n = min(sample_rows, index.ntotal)
+    try:  # the whole database when the host can hold it (SURVEY.md 8d), else a labelled sample
+        avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        avail = 0
+    if avail < 3 * n * d * 4:
+        n = min(n, 100_000)
     X = index.reconstruct_n(0, n)
     g = torch.Generator(device="cpu").manual_seed(97)
     Q = unit_queries(g, (100, d), "cpu").numpy()
@@ -318,11 +326,14 @@ def cpu_baseline_flat(index, d, k, sample_rows, n_total, dev):
             if time.perf_counter() - t0 > 5.0 or reps >= 8:
                 break
         dt100 = (time.perf_counter() - t0) / reps
-        out["batch_100_numpy_blas"] = {"qps_on_sample": 100 / dt100, "extrapolated_full_db_qps": 100 / dt100 * n / n_total,
+        out["batch_100_numpy_blas"] = {"qps_on_sample": 100 / dt100, "extrapolated_full_db_qps": 100 / dt100 * n / n_total, "rows_scanned": n,
                                        "what": f"numpy {np.__version__} Q(100,{d}) @ X({n},{d}).T + argpartition + sort, fp32; "
                                                f"BLAS threads decided by the numpy build (torch reports {torch_threads})"}
-    out["extrapolated_full_db_qps"] = out["value"] * n / n_total
-    out["extrapolation"] = f"linear in rows: value * {n}/{n_total} (a scan is DRAM-bound on the host)"
+    if n < n_total:
+        out["extrapolated_full_db_qps"] = out["value"] * n / n_total
+        out["extrapolation"] = f"linear in rows: value * {n}/{n_total} (a scan is DRAM-bound on the host)"
+    else:
+        out["rows_scanned"] = n   # the whole database of the bench line: nothing is extrapolated
     return out
 
 

@@ -5,7 +5,10 @@ PARITY UNPINNED (see oracle/__init__.py).  Follows:
     METRIC_INNER_PRODUCT); index.nprobe = config.nprobe)
   - /root/reference/core/index_factory.py:173-195  (train), :197-203 (min training size)
   - /root/reference/core/index_manager.py:284-319  (buffer -> train -> add), :371 (search)
-  - FAISS documented behaviour [FAISS-lib]: k-means with plain-mean centroids and
+  - FAISS documented behaviour [FAISS-lib]: SPHERICAL k-means (IndexIVF's constructor sets
+    ClusteringParameters::spherical when the metric is inner product: every centroid is
+    L2-normalised after the update + empty-cluster split of an iteration, and once after the
+    initialisation; `spherical=False` keeps plain means, what rounds 1-2 restated) with
     max-inner-product assignment (the quantizer is an IndexFlatIP), at most 256
     training points per centroid (random subsample), 10 iterations, random distinct
     training points as initial centroids; add() appends each vector to the list of
@@ -57,7 +60,15 @@ def search(X, C, labels, Q, k, nprobe, C_coarse=None, Q_coarse=None):
     return D, I, probes
 
 
-def kmeans(X, nlist, niter=10, seed=1234, max_points_per_centroid=256):
+def _renorm(C):
+    """[FAISS-lib] Clustering::post_process_centroids for spherical k-means: c / ||c||, zero rows left alone."""
+    nrm = np.sqrt((C.astype(np.float64) ** 2).sum(axis=1))
+    nz = nrm > 0
+    C[nz] = (C[nz] / nrm[nz, None]).astype(np.float32)
+    return C
+
+
+def kmeans(X, nlist, niter=10, seed=1234, max_points_per_centroid=256, spherical=True):
     """Restated FAISS-style k-means for the IP quantizer.  Returns (centroids, objective)
     where objective = mean over training points of the best inner product."""
     X = np.asarray(X, np.float32)
@@ -67,6 +78,8 @@ def kmeans(X, nlist, niter=10, seed=1234, max_points_per_centroid=256):
         X = X[np.sort(rng.choice(n, max_points_per_centroid * nlist, replace=False))]
         n = X.shape[0]
     C = X[rng.choice(n, nlist, replace=False)].copy()
+    if spherical:
+        _renorm(C)
     for _ in range(niter):
         lab = assign(X, C)
         counts = np.bincount(lab, minlength=nlist)
@@ -84,6 +97,8 @@ def kmeans(X, nlist, niter=10, seed=1234, max_points_per_centroid=256):
             C[big] = C[big] * (1 - sign * eps)
             counts[l] = counts[big] // 2
             counts[big] -= counts[l]
+        if spherical:
+            _renorm(C)
     return C, objective(X, C)
 
 

@@ -80,8 +80,12 @@ int RowStore::reserve(long long total, hipStream_t stream) {
         HIPCHECK(hipMalloc(&p, (size_t)cap * row_bytes));
         if (!segs.empty() && segs[0]) {
             const long long live = std::min(nrows, seg0_cap);
-            if (live > 0) HIPCHECK(hipMemcpyAsync(p, segs[0], (size_t)live * row_bytes, hipMemcpyDeviceToDevice, stream));
-            HIPCHECK(hipStreamSynchronize(stream));
+            hipError_t e = live > 0 ? hipMemcpyAsync(p, segs[0], (size_t)live * row_bytes, hipMemcpyDeviceToDevice, stream) : hipSuccess;
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) {  // the old segment stays the index's; the new block must not be lost
+                (void)hipFree(p);
+                return fail("growing segment 0 failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
+            }
             HIPCHECK(hipFree(segs[0]));
             segs[0] = p;
         } else if (segs.empty()) {

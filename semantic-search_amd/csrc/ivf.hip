@@ -140,6 +140,31 @@ __global__ void split_centroid_kernel(int ld, void* const* segs32, int shift32, 
     }
 }
 
+// [FAISS-lib] spherical k-means: IndexIVF sets ClusteringParameters::spherical for METRIC_INNER_PRODUCT, and
+// Clustering::post_process_centroids then L2-normalises every centroid (after the update and the empty-cluster
+// split of each iteration, and once after the initialisation); a zero centroid is left alone.  One block per centroid.
+__global__ void renorm_centroids_kernel(int ld, void* const* segs32, int shift32, void* const* segs16, int shift16) {
+    __shared__ float wsum[4];
+    const int l = blockIdx.x;
+    float* c32 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(segs32[l >> shift32]) +
+                                          (size_t)(l & ((1 << shift32) - 1)) * (size_t)ld * 4);
+    __half* c16 = reinterpret_cast<__half*>(reinterpret_cast<unsigned char*>(segs16[l >> shift16]) +
+                                            (size_t)(l & ((1 << shift16) - 1)) * (size_t)ld * 2);
+    float ss = 0.f;
+    for (int x = threadIdx.x; x < ld; x += blockDim.x) ss = fmaf(c32[x], c32[x], ss);
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float tot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (!(tot > 0.f)) return;
+    const float inv = 1.0f / sqrtf(tot);
+    for (int x = threadIdx.x; x < ld; x += blockDim.x) {
+        const float v = c32[x] * inv;
+        c32[x] = v;
+        c16[x] = __float2half(v);
+    }
+}
+
 // K7 (search side): per query, exclusive prefix sum of the probed lists' sizes.
 // prefix: (nq, nprobe+1) int64; one 256-thread block per query.
 __global__ void ivf_plan_kernel(const int64_t* __restrict__ Ic, int nprobe, const int* __restrict__ list_size,
@@ -486,6 +511,7 @@ int ivf_create(ssmi_index* h, int nlist) {
     h->nlist = nlist;
     h->nprobe = 1;  // FAISS default
     h->trained = false;
+    if (const char* e = getenv("SSMI_IVF_SPHERICAL")) S->spherical = e[0] != '0';
     if (S->cent32.init(h->rows.d, SSMI_F32, h->stream)) return 1;
     if (S->cent16.init(h->rows.d, SSMI_F16, h->stream)) return 1;
     S->pages.assign(nlist, {});
@@ -646,6 +672,14 @@ int ivf_train(ssmi_index* h, int64_t n, const float* x, int mem_kind) {
     HIPCHECK(hipStreamSynchronize(h->stream));
     CHECK(install_centroids(h, C0, SSMI_DEVICE));
     h->trained = false;
+    auto renorm = [&]() -> int {
+        if (!S->spherical) return 0;
+        hipLaunchKernelGGL(renorm_centroids_kernel, dim3(nlist), dim3(256), 0, h->stream, ld, (void* const*)S->cent32.d_segs,
+                           S->cent32.seg_shift, (void* const*)S->cent16.d_segs, S->cent16.seg_shift);
+        HIPCHECK(hipGetLastError());
+        return 0;
+    };
+    CHECK(renorm());
 
     // per iteration: K5 labels -> K7b buckets (perm, off) -> K6 means, all on the device; the host only sees the
     // nlist list sizes (for the empty-cluster fix)
@@ -685,6 +719,7 @@ int ivf_train(ssmi_index* h, int64_t n, const float* x, int mem_kind) {
             count[l] = count[big] / 2;
             count[big] -= count[l];
         }
+        CHECK(renorm());
         HIPCHECK(hipStreamSynchronize(h->stream));
     }
     h->trained = true;

@@ -28,10 +28,18 @@ struct IvfState {
     long long persist_base_ntotal = -1;    // ntotal in the base file's header
     unsigned long long persist_base_bytes = 0;  // size of the base file
     long long persist_journal_rows = 0;    // vectors the journal holds
+    // bytes of "<path>.journal" known to be a valid header + complete records for THIS base file (0: no journal, a
+    // foreign one, or one not looked at yet).  Appends start exactly there: a torn tail or a stale journal left by a
+    // crash is cut off / rewritten before anything is written behind it
+    unsigned long long persist_journal_bytes = 0;
     std::vector<long long> persist_size;   // per list: members already on disk (base + journal)
     int niter = 10;                   // [FAISS-lib] ClusteringParameters default for the IVF quantizer
     int max_points_per_centroid = 256;
     uint64_t seed = 1234;
+    // [FAISS-lib] IndexIVF's constructor makes the level-1 clustering spherical when the metric is inner product
+    // (centroids L2-normalised after every update); this index is inner-product only.  env SSMI_IVF_SPHERICAL=0
+    // keeps plain means (the round-1/2 behaviour)
+    bool spherical = true;
 };
 
 inline IvfState* st(ssmi_index* h) { return reinterpret_cast<IvfState*>(h->ivf); }

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <unistd.h>
 
 using namespace ssmi;
 
@@ -106,7 +107,16 @@ void record_full_state(ssmi_index* h, const char* path) {
     S->persist_base_ntotal = h->ivf_ntotal;
     S->persist_base_bytes = file_bytes(path);
     S->persist_journal_rows = 0;
+    S->persist_journal_bytes = 0;
     S->persist_size = S->size;
+}
+
+// does `f` (positioned at 0) start with the journal header of this index over this base file?
+bool journal_header_matches(FILE* f, int d, int nlist, long long base_ntotal, unsigned long long base_bytes) {
+    char cc[4];
+    int32_t jd; uint64_t jnlist, jbase_bytes; int64_t jbase_nt;
+    if (!(rd(f, cc, 4) && rd1(f, &jd) && rd1(f, &jnlist) && rd1(f, &jbase_nt) && rd1(f, &jbase_bytes))) return false;
+    return memcmp(cc, "SSJ1", 4) == 0 && jd == d && jnlist == (uint64_t)nlist && jbase_nt == base_ntotal && jbase_bytes == base_bytes;
 }
 
 // members each list gained since the last checkpoint -> one journal record
@@ -127,24 +137,50 @@ int append_journal(ssmi_index* h, const char* path) {
     HIPCHECK(hipMemcpy(sids.data(), S->d_slot_ids, sids.size() * 4, hipMemcpyDeviceToHost));
     std::vector<int64_t> ids64((size_t)n);
     for (int64_t i = 0; i < n; ++i) ids64[i] = (int64_t)sids[(size_t)slots[i]];
-    const bool fresh = file_bytes(jp.c_str()) < kJournalHeader;
+    // The record goes exactly behind the bytes this handle knows to be good (header of THIS base file + complete
+    // records): a torn tail left by a crash or a full disk is cut off first, and a journal that belongs to another
+    // base file (a crash between a base rewrite and the removal of its old journal) is started afresh - a record
+    // written behind either would be dropped, or misread, by the next read_index.
+    unsigned long long good = S->persist_journal_bytes;
     File F;
-    F.f = fopen(jp.c_str(), fresh ? "wb" : "ab");
-    if (!F.f) return fail("write_index: cannot open %s", jp.c_str());
+    if (good >= kJournalHeader) {
+        F.f = fopen(jp.c_str(), "r+b");
+        if (!F.f || file_bytes(jp.c_str()) < good ||
+            !journal_header_matches(F.f, R.d, h->nlist, S->persist_base_ntotal, S->persist_base_bytes)) {
+            // the journal this handle wrote is gone or was replaced behind its back: its records cannot be trusted
+            // any more, so the whole index is written again
+            if (F.f) { fclose(F.f); F.f = nullptr; }
+            return ssmi_index_write(h, path);
+        }
+        if (fflush(F.f) != 0 || ftruncate(fileno(F.f), (off_t)good) != 0 || fseek(F.f, (long)good, SEEK_SET) != 0)
+            return fail("write_index: cannot position %s", jp.c_str());
+    } else {
+        F.f = fopen(jp.c_str(), "wb");
+        if (!F.f) return fail("write_index: cannot open %s", jp.c_str());
+        if (!(wr(F.f, "SSJ1", 4) && wr1<int32_t>(F.f, R.d) && wr1<uint64_t>(F.f, (uint64_t)h->nlist) &&
+              wr1<int64_t>(F.f, S->persist_base_ntotal) && wr1<uint64_t>(F.f, S->persist_base_bytes)) || fflush(F.f) != 0)
+            return fail("write_index: journal write failed");
+        good = kJournalHeader;
+        S->persist_journal_bytes = good;
+    }
     FILE* f = F.f;
-    if (fresh && !(wr(f, "SSJ1", 4) && wr1<int32_t>(f, R.d) && wr1<uint64_t>(f, (uint64_t)h->nlist) &&
-                   wr1<int64_t>(f, S->persist_base_ntotal) && wr1<uint64_t>(f, S->persist_base_bytes)))
-        return fail("write_index: journal write failed");
+    // a record that fails part-way is taken back, so the file never keeps half a record in front of a later one
+    auto undo = [&](const char* what) -> int {
+        (void)fflush(f);
+        (void)!ftruncate(fileno(f), (off_t)good);
+        return fail("write_index: %s for %s", what, jp.c_str());
+    };
     if (!(wr(f, "chnk", 4) && wr1<uint64_t>(f, (uint64_t)n) && wr(f, labels.data(), (size_t)n * 4) && wr(f, ids64.data(), (size_t)n * 8)))
-        return fail("write_index: journal write failed");
+        return undo("journal write failed");
     const int64_t chunk = std::max<int64_t>(1, ((size_t)64 << 20) / ((size_t)R.d * 4));
     std::vector<float> buf((size_t)std::min(chunk, n) * R.d);
     for (int64_t done = 0; done < n; done += chunk) {
         const int64_t cnt = std::min(chunk, n - done);
-        CHECK(read_rows(h, R, h->ivf_slots_used, slots.data() + done, cnt, buf.data()));
-        if (!wr(f, buf.data(), (size_t)cnt * R.d * 4)) return fail("write_index: journal write failed");
+        if (read_rows(h, R, h->ivf_slots_used, slots.data() + done, cnt, buf.data())) { (void)fflush(f); (void)!ftruncate(fileno(f), (off_t)good); return 1; }
+        if (!wr(f, buf.data(), (size_t)cnt * R.d * 4)) return undo("journal write failed");
     }
-    if (fflush(f) != 0) return fail("write_index: flush failed for %s", jp.c_str());
+    if (fflush(f) != 0) return undo("flush failed");
+    S->persist_journal_bytes = good + 12 + (unsigned long long)n * (4 + 8 + (unsigned long long)R.d * 4);
     S->persist_journal_rows += n;
     S->persist_size = S->size;
     return 0;
@@ -162,12 +198,10 @@ int replay_journal(ssmi_index* h, const char* path, int64_t base_ntotal) {
     if (!F.f) return 0;
     FILE* f = F.f;
     char cc[4];
-    int32_t jd; uint64_t jnlist, jbase_bytes; int64_t jbase_nt;
-    if (!(rd(f, cc, 4) && rd1(f, &jd) && rd1(f, &jnlist) && rd1(f, &jbase_nt) && rd1(f, &jbase_bytes))) return 0;
-    if (memcmp(cc, "SSJ1", 4) != 0 || jd != d || jnlist != (uint64_t)h->nlist || jbase_nt != base_ntotal ||
-        jbase_bytes != file_bytes(path))
-        return 0;  // belongs to an earlier base file: stale, the base alone is the index
+    if (!journal_header_matches(f, d, h->nlist, base_ntotal, file_bytes(path)))
+        return 0;  // belongs to an earlier base file: stale, the base alone is the index (the next append rewrites it)
     unsigned long long pos = kJournalHeader;
+    S->persist_journal_bytes = pos;  // header is ours; complete records extend it below, a torn tail does not
     const uint64_t rec = 4 + 8 + (uint64_t)d * 4;
     const int64_t chunk = std::max<int64_t>(1, ((size_t)64 << 20) / ((size_t)d * 4));
     std::vector<int32_t> labels; std::vector<int64_t> ids64; std::vector<uint32_t> ids32; std::vector<float> buf; std::vector<int> lab;
@@ -194,6 +228,7 @@ int replay_journal(ssmi_index* h, const char* path, int64_t base_ntotal) {
         }
         S->persist_journal_rows += (long long)n;
         pos = vec0 + n * (uint64_t)d * 4;
+        S->persist_journal_bytes = pos;
     }
     return 0;
 }
@@ -471,6 +506,7 @@ int ssmi_index_read(const char* path, int storage_dtype, int device, ssmi_index*
     S->persist_base_ntotal = ntotal;
     S->persist_base_bytes = file_bytes(path);
     S->persist_journal_rows = 0;
+    S->persist_journal_bytes = 0;
     CHECK(replay_journal(h, path, ntotal));
     S->persist_size = S->size;
     guard.h = nullptr;

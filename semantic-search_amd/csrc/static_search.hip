@@ -80,6 +80,9 @@ int ssmi_index_search_static(ssmi_index* h, int64_t nq, const float* q_dev, int 
     }
     if (!base) return fail("search_static: static scratch of device %d was never set up", h->device);
     hipStream_t s = (hipStream_t)stream;
+    // host bookkeeping + at most one event wait (allocates nothing): add / write / free on this handle wait for this
+    // launch like for any other search (quiesce), and a search still running on another stream stays ordered
+    CHECK(order_search_on(h, s));
     if (R.nrows == 0) {
         HIPCHECK(launch_fill_empty(D_dev, I_dev, nq * k, s));
         return 0;

@@ -41,6 +41,22 @@ _STORAGE = {"f32": _lib.F32, "fp32": _lib.F32, "float32": _lib.F32, "f16": _lib.
             "float16": _lib.F16}
 
 
+def _floor32(min_score) -> float:
+    """The fp32 floor the kernels compare with, chosen so that `score_f32 >= floor` decides exactly what the
+    reference's `r.score >= min_score` decides in double precision (nodes/search_nodes.py:152-159): the SMALLEST
+    float32 that is >= min_score.  Plain narrowing rounds to nearest, which keeps a score one ulp below a floor
+    that rounded down (and drops one equal to a floor that rounded up)."""
+    if min_score is None:
+        return _NO_FLOOR
+    m = float(min_score)
+    if m != m:
+        raise RuntimeError("search: min_score is NaN")
+    f = np.float32(m)
+    if np.isfinite(f) and float(f) < m:
+        f = np.nextafter(f, np.float32(np.inf), dtype=np.float32)
+    return max(float(f), _NO_FLOOR) if np.isfinite(f) else (_NO_FLOOR if m < 0 else float(np.finfo(np.float32).max))
+
+
 def _default_device() -> int:
     env = os.environ.get("SSMI_DEVICE")
     if env is not None:
@@ -169,7 +185,7 @@ class _IndexBase:
         k = int(k)
         if k < 1:
             raise RuntimeError("search: k must be >= 1")
-        floor = _NO_FLOOR if min_score is None else float(min_score)
+        floor = _floor32(min_score)
         if isinstance(x, torch.Tensor) and x.is_cuda:
             if x.dim() == 1:
                 x = x.reshape(1, -1)

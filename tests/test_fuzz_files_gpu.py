@@ -125,3 +125,54 @@ def test_nprobe_field_of_an_ivf_file(ssa, tmp_path):
         if outcome >= 9:      # every list probed: the exact result
             np.testing.assert_array_equal(I, exact)
         ix.close()
+
+
+def test_append_after_a_torn_or_stale_journal_keeps_every_vector(ssa, tmp_path):
+    """Incremental checkpoints behind a damaged journal (found by review, round 2): a record appended behind a torn
+    tail was dropped or misread by the next read, and one appended to the journal of an older base file was ignored.
+    Now the append starts at the last byte known good (torn tail cut off) or rewrites a foreign journal's header."""
+    d, X, pf, pi = _make_files(ssa, tmp_path)        # base 600 rows + records of 200 and 100
+    jp = str(pi) + ".journal"
+    raw = open(jp, "rb").read()
+    extra = unit_rows(50, d, 77)
+    rec1_end = 28 + 12 + 200 * (4 + 8 + d * 4)
+    assert len(raw) == rec1_end + 12 + 100 * (4 + 8 + d * 4)
+    for cut in (rec1_end + 5, rec1_end + 12 + 37, len(raw) - 1, 28 + 3, 11):
+        open(jp, "wb").write(raw[:cut])
+        ix = ssa.read_index(pi)
+        kept = ix.ntotal
+        assert kept == (800 if cut >= rec1_end else 600), (cut, kept)
+        ix.add(extra)
+        ssa.write_index(ix, pi, incremental=True)
+        ix.close()
+        back = ssa.read_index(pi)
+        assert back.ntotal == kept + 50, (cut, back.ntotal)
+        Dq, Iq = back.search(extra[:4], 1)
+        np.testing.assert_array_equal(Iq[:, 0], np.arange(kept, kept + 4))
+        back.add(extra); ssa.write_index(back, pi, incremental=True); back.close()   # and the reloaded handle goes on
+        again = ssa.read_index(pi)
+        assert again.ntotal == kept + 100
+        again.close()
+        # restore the starting point: base of 600 + the two records
+        ivf = ssa.IndexIVFFlat(ssa.IndexFlatIP(d), d, 9, ssa.METRIC_INNER_PRODUCT)
+        ivf.set_centroids(unit_rows(9, d, 6)); ivf.add(X[:600]); ssa.write_index(ivf, pi)
+        open(jp, "wb").write(raw)
+        assert ssa.read_index(pi).ntotal == 900
+    # a stale journal of an OLDER base (crash between the base rewrite and the removal of its journal)
+    ivf = ssa.IndexIVFFlat(ssa.IndexFlatIP(d), d, 9, ssa.METRIC_INNER_PRODUCT)
+    ivf.set_centroids(unit_rows(9, d, 6)); ivf.add(X[:700]); ssa.write_index(ivf, pi); ivf.close()
+    open(jp, "wb").write(raw)                        # header names the 600-row base
+    ix = ssa.read_index(pi)
+    assert ix.ntotal == 700
+    ix.add(extra); ssa.write_index(ix, pi, incremental=True); ix.close()
+    back = ssa.read_index(pi)
+    assert back.ntotal == 750
+    np.testing.assert_array_equal(back.search(extra[:4], 1)[1][:, 0], np.arange(700, 704))
+    back.close()
+    # the journal disappears under a live handle that already appended to it: the checkpoint rewrites the base
+    ivf = ssa.IndexIVFFlat(ssa.IndexFlatIP(d), d, 9, ssa.METRIC_INNER_PRODUCT)
+    ivf.set_centroids(unit_rows(9, d, 6)); ivf.add(X[:600]); ssa.write_index(ivf, pi)
+    ivf.add(X[600:700]); ssa.write_index(ivf, pi, incremental=True)
+    (tmp_path / "ivf.faiss.journal").unlink()
+    ivf.add(X[700:750]); ssa.write_index(ivf, pi, incremental=True)
+    assert ssa.read_index(pi).ntotal == 750

@@ -90,7 +90,13 @@ def test_large_query_batch_uses_mfma_coarse_quantizer(ssa):
     assert ok, msg
 
 
-def test_train_kmeans_quality_and_recall(ssa):
+@pytest.mark.parametrize("spherical", [True, False])
+def test_train_kmeans_quality_and_recall(ssa, monkeypatch, spherical):
+    """train() = k-means of the coarse quantizer (core/index_factory.py:191).  Default: spherical, what FAISS's
+    IndexIVF does for METRIC_INNER_PRODUCT (core/index_factory.py:144-146) [FAISS-lib, parity unpinned]: centroids
+    come back L2-normalised; SSMI_IVF_SPHERICAL=0 (read when the index is created) keeps plain means."""
+    if not spherical:
+        monkeypatch.setenv("SSMI_IVF_SPHERICAL", "0")
     n, d, nlist = 20000, 256, 50
     X = clustered_rows(n, d, 50, 31)
     index = make_ivf(ssa, d, nlist)
@@ -104,11 +110,17 @@ def test_train_kmeans_quality_and_recall(ssa):
     index.train(X)
     assert index.is_trained
     C = index.get_centroids()
-    _, obj_ref = ivf_flat.kmeans(X, nlist)
+    norms = np.linalg.norm(C.astype(np.float64), axis=1)
+    if spherical:
+        np.testing.assert_allclose(norms, 1.0, atol=2e-6)
+    else:
+        assert norms.max() < 0.999   # means of unit rows that do not coincide lie inside the sphere
+    _, obj_ref = ivf_flat.kmeans(X, nlist, spherical=spherical)
     obj = ivf_flat.objective(X, C)
     assert obj > 0.97 * obj_ref, (obj, obj_ref)
     index.add(X)
     assert int(index.list_sizes().sum()) == n
+    assert ivf_flat.assignment_is_valid(X, C, index.assignments(), rtol=2e-3)
     Q = clustered_rows(100, d, 50, 32)
     index.nprobe = 10
     D, I = index.search(Q, 10)
@@ -116,6 +128,24 @@ def test_train_kmeans_quality_and_recall(ssa):
     recall = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(I, Ir)])
     assert recall > 0.9, recall
     assert (np.diff(D, axis=1) <= 0).all()
+
+
+def test_spherical_kmeans_on_rows_of_unequal_norm(ssa):
+    """Rows that are NOT unit vectors: plain means keep the scale of their members, so with max-inner-product
+    assignment the long clusters' centroids attract everything; spherical centroids (FAISS's choice for the inner
+    product) compare by direction only.  Checked against the oracle's k-means in the same mode."""
+    n, d, nlist = 12000, 128, 24
+    rng = np.random.default_rng(77)
+    X = clustered_rows(n, d, nlist, 33) * rng.uniform(0.5, 4.0, (n, 1)).astype(np.float32)
+    index = make_ivf(ssa, d, nlist)
+    index.train(X)
+    C = index.get_centroids()
+    np.testing.assert_allclose(np.linalg.norm(C.astype(np.float64), axis=1), 1.0, atol=2e-6)
+    _, obj_ref = ivf_flat.kmeans(X, nlist, spherical=True)
+    assert ivf_flat.objective(X, C) > 0.97 * obj_ref
+    index.add(X)
+    sizes = index.list_sizes()
+    assert sizes.max() < 6 * n / nlist, sizes   # no list swallows the index
 
 
 def test_reconstruct_needs_direct_map(ssa):
