@@ -179,73 +179,102 @@ class IndexFactory:
     _CHUNK_ROWS = 65536  # rows moved per step (1 GiB of fp32 at d = 4096), all of it in HBM
 
     @staticmethod
-    def _build_from_index(old_index, ids: np.ndarray, config: IndexConfig):
-        """New index holding the vectors `ids` of old_index in that order, DEVICE-RESIDENT: rows are gathered on
-        the GPU (ssmi_index_reconstruct_n_dev) and handed to train()/add() as device tensors chunk by chunk, so no
-        (N, d) host array exists at any point (the reference's loops: core/index_factory.py:273-274,371-372 fill
-        one).  Raises RuntimeError when the old index cannot reconstruct (IVF without a
-        direct map), like the reference's reconstruct() does."""
-        index = IndexFactory.create_index(config)
+    def _first_unreadable(old_index, ids: np.ndarray) -> int:
+        """Position in `ids` of the first vector old_index.reconstruct would refuse (len(ids) if none): the reference
+        walks the ids one reconstruct() at a time and stops at the first RuntimeError (core/index_factory.py:271-278,
+        369-378); here the vectors move later, on the device, so the same answer is worked out up front - an IVF index
+        without a direct map refuses every id, any index refuses ids outside [0, ntotal)."""
+        if len(ids) == 0:
+            return 0
+        bad = np.nonzero((ids < 0) | (ids >= old_index.ntotal))[0]
+        first_bad = int(bad[0]) if len(bad) else len(ids)
+        if first_bad > 0:
+            try:
+                old_index.reconstruct_batch_device(ids[:1])
+            except RuntimeError:
+                return 0
+        return first_bad
+
+    @staticmethod
+    def _train_and_fill(index, old_index, ids: np.ndarray, config: IndexConfig, report, n_done: int, status: Optional[str]):
+        """Shared tail of rebuild_index / compact_index (core/index_factory.py:286-307, 394-411): train on all vectors
+        or on a sample of 100000 drawn like the reference draws it (np.random.choice without replacement, used in the
+        order drawn), fall back to Flat when training fails, add.  DEVICE-RESIDENT: rows are gathered on the GPU
+        (ssmi_index_reconstruct_n_dev) and handed to train()/add() as device tensors chunk by chunk, so no (N, d) host
+        array exists at any point."""
         n = len(ids)
         if IndexFactory.needs_training(index):
+            report(n_done, n, status)
             sample = ids
             if n > _TRAIN_SAMPLE_CAP:
-                sample = np.sort(ids[np.random.choice(n, _TRAIN_SAMPLE_CAP, replace=False)])
+                sample = ids[np.random.choice(n, _TRAIN_SAMPLE_CAP, replace=False)]
             ok = False
             try:
                 index.train(old_index.reconstruct_batch_device(sample))
                 ok = bool(index.is_trained)
-            except RuntimeError as e:
-                if "reconstruct" in str(e) or "direct map" in str(e):
-                    raise
+            except Exception as e:  # the reference's train_index swallows everything (core/index_factory.py:193-195)
                 print(f"[SemanticSearch] Index training failed: {e}")
             if not ok:
                 print("[SemanticSearch] Warning: Training failed, falling back to Flat index")
                 config.index_type = IndexType.FLAT
                 index = IndexFactory.create_index(config)
-        for s0 in range(0, n, IndexFactory._CHUNK_ROWS):
-            index.add(old_index.reconstruct_batch_device(ids[s0:s0 + IndexFactory._CHUNK_ROWS]))
         return index
 
     @staticmethod
+    def _fill(index, old_index, ids: np.ndarray) -> None:
+        for s0 in range(0, len(ids), IndexFactory._CHUNK_ROWS):
+            index.add(old_index.reconstruct_batch_device(ids[s0:s0 + IndexFactory._CHUNK_ROWS]))
+
+    @staticmethod
     def rebuild_index(old_index, new_config: IndexConfig, progress_callback: ProgressCallback = None) -> Tuple[Any, bool]:
-        """core/index_factory.py:240-312.  Returns (new_index, True) or (old_index, False)."""
+        """core/index_factory.py:240-312.  Returns (new_index, True) or (old_index, False); the progress callback sees
+        the reference's sequence: (0, "Extracting..."), (n/2, "Creating new index..."), (n/2, "Training new index...")
+        only when the index just created asks for training, (3n/4, "Adding..."), (n, "Rebuild complete")."""
         n = old_index.ntotal
         report = progress_callback or (lambda *a: None)
         if n == 0:
             return IndexFactory.create_index(new_config), True
         report(0, n, "Extracting vectors from old index...")
-        try:
-            old_index.reconstruct_batch_device(np.zeros((1,), dtype=np.int64))   # can this index give its vectors back?
-        except RuntimeError:
+        ids = np.arange(n, dtype=np.int64)
+        if IndexFactory._first_unreadable(old_index, ids) < n:
             print("[SemanticSearch] Warning: Cannot reconstruct vectors from this index type")
             return old_index, False
         report(n // 2, n, "Creating new index...")
-        if new_config.index_type in (IndexType.IVF_FLAT, IndexType.IVF_PQ):
-            report(n // 2, n, "Training new index...")
+        new_index = IndexFactory.create_index(new_config)
+        new_index = IndexFactory._train_and_fill(new_index, old_index, ids, new_config, report, n // 2, "Training new index...")
         report(n * 3 // 4, n, "Adding vectors to new index...")
-        new_index = IndexFactory._build_from_index(old_index, np.arange(n, dtype=np.int64), new_config)
+        IndexFactory._fill(new_index, old_index, ids)
         report(n, n, "Rebuild complete")
         return new_index, True
 
     @staticmethod
     def compact_index(old_index, valid_vector_ids: List[int], new_config: Optional[IndexConfig] = None,
                       progress_callback: ProgressCallback = None) -> Tuple[Any, Dict[int, int], bool]:
-        """core/index_factory.py:322-416.  Keeps sorted(valid ids), renumbers them 0..n-1."""
+        """core/index_factory.py:322-416.  Keeps sorted(valid ids), renumbers them 0..n-1; the progress callback sees
+        the reference's sequence, the "Extracted i/n vectors..." report after every 1000 vectors included."""
         n_valid, n_total = len(valid_vector_ids), old_index.ntotal
         report = progress_callback or (lambda *a: None)
-        if new_config is None:
-            new_config = IndexConfig(index_type=IndexFactory.detect_index_type(old_index), dimension=old_index.d)
         if n_valid == 0:
+            if new_config is None:
+                new_config = IndexConfig(index_type=IndexFactory.detect_index_type(old_index), dimension=old_index.d)
             return IndexFactory.create_index(new_config), {}, True
         report(0, n_valid, f"Extracting {n_valid} vectors (removing {n_total - n_valid} deleted)...")
         keep = sorted(valid_vector_ids)
         id_mapping = {old: new for new, old in enumerate(keep)}
-        try:
-            report(n_valid, n_valid, "Creating compacted index...")
-            new_index = IndexFactory._build_from_index(old_index, np.asarray(keep, dtype=np.int64), new_config)
-        except RuntimeError as e:
-            print(f"[SemanticSearch] Warning: Cannot reconstruct vectors: {e}")
+        ids = np.asarray(keep, dtype=np.int64)
+        readable = IndexFactory._first_unreadable(old_index, ids)
+        for done in range(1000, readable + 1, 1000):
+            report(done, n_valid, f"Extracted {done}/{n_valid} vectors...")
+        if readable < n_valid:
+            why = (f"id {int(ids[readable])} out of range [0, {n_total})" if 0 < readable or not (0 <= ids[0] < n_total)
+                   else "this index has no direct map")
+            print(f"[SemanticSearch] Warning: Cannot reconstruct vectors: {why}")
             return old_index, {}, False
+        report(n_valid, n_valid, "Creating compacted index...")
+        if new_config is None:
+            new_config = IndexConfig(index_type=IndexFactory.detect_index_type(old_index), dimension=old_index.d)
+        new_index = IndexFactory.create_index(new_config)
+        new_index = IndexFactory._train_and_fill(new_index, old_index, ids, new_config, report, n_valid, "Training compacted index...")
+        IndexFactory._fill(new_index, old_index, ids)
         report(n_valid, n_valid, f"Compaction complete: {n_total} -> {n_valid} vectors")
         return new_index, id_mapping, True

@@ -144,3 +144,88 @@ def test_configs4_per_shard_shape_through_gather_and_merge(ssa, one_rank_group):
     torch.cuda.synchronize()
     assert np.array_equal(Im2.cpu().numpy(), Im) and np.array_equal(Dm2.cpu().numpy(), Dm)
     local.close()
+
+
+def _clustered_device_rows(d, n_total, seed, dev, ncl=16384, sigma=0.6):
+    """The bench's clustered generator (bench.py: ivf_rows_factory): unit rows around `ncl` shared random centres."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    gc = torch.Generator(device=dev).manual_seed(999)
+    centres = torch.randn((ncl, d), generator=gc, device=dev)
+    centres /= centres.norm(dim=1, keepdim=True)
+
+    def rows(m):
+        x = torch.randn((m, d), generator=g, device=dev) * (sigma / d ** 0.5)
+        x += centres[torch.randint(0, ncl, (m,), generator=g, device=dev)]
+        return x / x.norm(dim=1, keepdim=True)
+    return rows
+
+
+def test_configs4_ivf_leg_list_sharded_at_the_per_gpu_shard_size(ssa, one_rank_group):
+    """BASELINE configs[4], IVF leg, one GPU's share of it: IVF4096 over 12.5M x 4096 fp16 rows through
+    ShardedIVFFlat on a one-rank RCCL group with the collectives forced on (broadcast centroids, routed add =
+    assign -> all-to-all -> append, gathered search), nprobe 32, against a row-sharded Flat twin of the same
+    rows.  Full-size properties: returned scores re-scored in float64 from the twin's stored rows, every IVF hit that
+    beats the twin's k-th score is one of the twin's hits, recall@10 >= 0.98 (clustered rows: IVF's use case),
+    batch 1 (per-query scan) and a batch that takes the list-major matrix-core scan, idempotence."""
+    from semantic_search_amd.sharded import ShardedFlatIP, ShardedIVFFlat
+    n, d, nlist, nprobe, k = 12_500_000, 4096, 4096, 32, 10
+    dev = torch.device("cuda", 0)
+    off = 5 * n                                            # rank 5's rows of the 100M-row database
+    ivf = ShardedIVFFlat(d, nlist, storage="f16", device=0)
+    flat = ShardedFlatIP(d, storage="f16", device=0)
+    ivf._force_pipeline = flat._force_pipeline = True
+    ivf.train(_clustered_device_rows(d, n, 99, dev)(256 * nlist // 4))     # 64 points per centroid keep the test short
+    assert ivf.is_trained
+    rows = _clustered_device_rows(d, n, 1234 + 5, dev)
+    for s0 in range(0, n, 65536):
+        m = min(65536, n - s0)
+        x = rows(m)
+        ivf.add_local(x, ids=np.arange(off + s0, off + s0 + m, dtype=np.int64))
+        flat.add_local(x.half())
+    del x
+    flat.finalize(device=dev)
+    flat.row_offset = off
+    assert ivf.ntotal == n and ivf.local.ntotal == n and flat.ntotal == n
+    sizes = ivf.local.list_sizes()
+    assert int(sizes.sum()) == n and sizes.max() < 40 * n / nlist
+    ivf.nprobe = nprobe
+    Q = _clustered_device_rows(d, n, 4321, dev)(512)
+    # batch 1
+    nq1 = 24
+    D1 = np.zeros((nq1, k), np.float32); I1 = np.zeros((nq1, k), np.int64)
+    for qi in range(nq1):
+        a, b = ivf.search(Q[qi:qi + 1], k)
+        D1[qi], I1[qi] = a.cpu().numpy()[0], b.cpu().numpy()[0]
+    t = ivf.local.last_timing()
+    assert t["last_path"] == 2 and "ivf_scan" in ivf.local.last_kernel()
+    Df, If = flat.search(Q, k)
+    torch.cuda.synchronize()
+    Df, If = Df.cpu().numpy(), If.cpu().numpy()
+    Qh = Q.cpu().numpy()
+
+    def check(D, I, sel, rtol, atol):
+        assert (np.diff(D, axis=1) <= 0).all()
+        valid = I >= 0
+        assert ((I[valid] >= off) & (I[valid] < off + n)).all()
+        for j, qi in enumerate(sel):
+            v = valid[j]
+            got = flat.local.reconstruct_batch(I[j][v] - off).astype(np.float64) @ Qh[qi].astype(np.float64)
+            np.testing.assert_allclose(D[j][v], got, rtol=rtol, atol=atol)
+            beats = I[j][v][D[j][v] > Df[qi, -1] * (1 + rtol) + atol]
+            assert set(beats.tolist()) <= set(If[qi].tolist()), f"query {qi}: an IVF hit above the Flat k-th score is not a Flat hit"
+        return float(np.mean([len(set(I[j].tolist()) & set(If[qi].tolist())) / k for j, qi in enumerate(sel)]))
+    r1 = check(D1, I1, list(range(nq1)), 1e-5, 2e-6)
+    assert r1 >= 0.98, r1
+    # a batch on the list-major matrix-core scan (fp16 queries: the north-star tolerance)
+    Db, Ib = ivf.search(Q, k)
+    torch.cuda.synchronize()
+    assert ivf.local.last_kernel() == "ivf_scan_lists_mfma_kernel"
+    Db, Ib = Db.cpu().numpy(), Ib.cpu().numpy()
+    sel = list(range(0, 512, 16))
+    rb = check(Db[sel], Ib[sel], sel, 1e-3, 1e-4)
+    assert rb >= 0.98, rb
+    np.testing.assert_allclose(Db[:nq1], D1, rtol=1e-3, atol=1e-4)
+    Db2, Ib2 = ivf.search(Q, k)
+    torch.cuda.synchronize()
+    assert np.array_equal(Ib2.cpu().numpy(), Ib) and np.array_equal(Db2.cpu().numpy(), Db)
+    ivf.local.close(); flat.local.close()
