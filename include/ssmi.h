@@ -43,6 +43,11 @@ typedef struct ssmi_index ssmi_index;
 /* element types */
 #define SSMI_F32 0
 #define SSMI_F16 1
+/* bfloat16 rows.  The reference's producer emits bf16 model outputs cast to fp32 (core/model_wrapper.py:201-203), so
+ * for its embeddings bf16 storage is LOSSLESS at half the bytes of fp32: reconstruct returns the input bit for bit
+ * and every search path returns the fp32 result up to summation order.  Other fp32 values are rounded to nearest
+ * even at add (8 significant bits: coarser than SSMI_F16's 11). */
+#define SSMI_BF16 2
 /* where a caller buffer lives */
 #define SSMI_HOST 0
 #define SSMI_DEVICE 1
@@ -197,16 +202,23 @@ int ssmi_index_get_timing(const ssmi_index* h, ssmi_timing* out);
 /* hipEvent durations (ms) of the dominant kernel (scan / contraction) of the last
  * min(max_n, 256) searches on this handle, oldest first (bench.py's roofline leg). */
 int ssmi_index_get_scan_times(const ssmi_index* h, int max_n, float* ms_out, int* n_out);
-/* The fp16 shadow (no reference counterpart).  Query batches of >= 9 over an fp32 index (Flat; IVF when the
- * batch revisits lists) run on the matrix cores, which need fp16 operands: the first such search builds an fp16
- * copy of the rows (+50 % HBM), later adds keep it in step, and those batches then carry fp16 rounding of rows
- * and queries (scores within ~1e-4 relative, ids may swap at near-ties; batches of <= 8 stay exact).
+/* The 16-bit shadow (no reference counterpart).  Query batches of >= 9 over an fp32 index (Flat; IVF when the
+ * batch revisits lists) run on the matrix cores, which need 16-bit operands: the first such search builds a 16-bit
+ * copy of the rows (+50 % HBM; fp16, or bf16 when that is lossless: ssmi_index_get_shadow_dtype), later adds keep it
+ * in step, and those batches then carry that rounding of rows and queries (fp16: scores within ~1e-4 relative, ids
+ * may swap at near-ties; batches of <= 8 stay exact).
  * policy 1 (default): build it on demand; if it does not fit in HBM the search falls back to the exact fp32
  * scan instead of failing.  policy 0: never - every batch stays exact; an existing shadow is freed.
  * get_shadow_state: the policy, how many rows the shadow currently holds (0 = none), and whether the last
  * attempt to build it ran out of memory. */
 int ssmi_index_set_shadow_policy(ssmi_index* h, int policy);
 int ssmi_index_get_shadow_state(const ssmi_index* h, int* policy, int64_t* shadow_rows, int* failed);
+/* Element type of the shadow: SSMI_F16 or SSMI_BF16, -1 while there is none.  By default it is bf16 as long as every
+ * fp32 row is bf16-valued (what the reference's embedder produces: bf16 model outputs cast to fp32,
+ * core/model_wrapper.py:201-203) - the shadow is then an exact copy and batched searches return the exact scan's ids
+ * for bf16-valued queries - and fp16 otherwise; env SSMI_SHADOW_DTYPE=f16|bf16|auto fixes it.  No reference
+ * counterpart. */
+int ssmi_index_get_shadow_dtype(const ssmi_index* h, int* out);
 /* name of the dominant kernel (scan / contraction) the last search on this handle launched: a static string
  * owned by the library, "" before the first search (bench.py labels its roofline with it; rocprofv3 traces
  * show the same name). */

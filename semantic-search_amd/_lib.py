@@ -17,7 +17,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "csrc" / "libssmi.so"
 
-F32, F16 = 0, 1
+F32, F16, BF16 = 0, 1, 2
 HOST, DEVICE = 0, 1
 KIND_FLAT, KIND_IVFFLAT = 0, 1
 MAX_K = 1024
@@ -84,6 +84,7 @@ _SIGNATURES = {
     "ssmi_index_set_shadow_policy": [_c_index_p, ctypes.c_int],
     "ssmi_index_get_shadow_state": [_c_index_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64),
                                     ctypes.POINTER(ctypes.c_int)],
+    "ssmi_index_get_shadow_dtype": [_c_index_p, ctypes.POINTER(ctypes.c_int)],
     "ssmi_index_get_last_kernel": [_c_index_p, ctypes.POINTER(ctypes.c_char_p)],
     "ssmi_index_set_timing": [_c_index_p, ctypes.c_int],
     "ssmi_index_get_list_sizes": [_c_index_p, ctypes.c_void_p],

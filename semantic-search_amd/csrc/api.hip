@@ -36,7 +36,7 @@ namespace ssmi {
 int RowStore::init(int d_, int dtype_, hipStream_t stream) {
     d = d_;
     dtype = dtype_;
-    elsize = dtype == SSMI_F32 ? 4 : 2;
+    elsize = (size_t)dtype_elsize(dtype);
     ld = (d + 7) / 8 * 8;
     row_bytes = (size_t)ld * elsize;
     // ~1 GiB segments, between 2^10 and 2^24 rows
@@ -158,7 +158,7 @@ static int create_common(int d, int storage_dtype, int device, int kind, ssmi_in
     if (!out) return fail("out is NULL");
     *out = nullptr;
     if (d < 1 || d > 65536) return fail("dimension %d out of range [1, 65536]", d);
-    if (storage_dtype != SSMI_F32 && storage_dtype != SSMI_F16) return fail("unknown storage dtype %d", storage_dtype);
+    if (!dtype_known(storage_dtype)) return fail("unknown storage dtype %d", storage_dtype);
     int ndev = 0;
     HIPCHECK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail("device %d not available (%d visible)", device, ndev);
@@ -188,6 +188,8 @@ static int create_common(int d, int storage_dtype, int device, int kind, ssmi_in
         HIPCHECK(zero_device_sync(h->tail_counters, ssmi_index::kTailCounters * sizeof(unsigned), h->stream));
     }
     if (const char* e = getenv("SSMI_TIMING")) h->timing_on = e[0] != '0';
+    if (const char* e = getenv("SSMI_SHADOW_DTYPE")) h->shadow_pref = !strcmp(e, "f16") ? SSMI_F16 : (!strcmp(e, "bf16") ? SSMI_BF16 : -1);
+    HIPCHECK(hipMalloc((void**)&h->d_flag, 256));
     CHECK(h->rows.init(d, storage_dtype, h->stream));
     guard.h = nullptr;
     *out = h;
@@ -250,6 +252,7 @@ int ssmi_index_free(ssmi_index* h) {
     if (h->has_shadow) h->shadow16.destroy();
     for (int i = 0; i < kWsSlots; ++i) if (h->ws[i]) (void)hipFree(h->ws[i]);
     if (h->tail_counters) (void)hipFree(h->tail_counters);
+    if (h->d_flag) (void)hipFree(h->d_flag);
     if (h->pin) (void)hipHostFree(h->pin);
     for (int i = 0; i < ssmi_index::kEvRing; ++i)
         for (int j = 0; j < 3; ++j) if (h->ev[i][j]) (void)hipEventDestroy(h->ev[i][j]);
@@ -306,7 +309,7 @@ int store_add(ssmi_index* h, RowStore& R, int64_t n, const void* x, int src_dtyp
     const long long row0 = R.nrows;
     if ((unsigned long long)(row0 + n) >= 0xFFFFFFFFull) return fail("index would exceed 2^32-2 vectors");
     CHECK(R.reserve(row0 + n, h->stream));
-    const size_t src_el = src_dtype == SSMI_F32 ? 4 : 2;
+    const size_t src_el = (size_t)dtype_elsize(src_dtype);
     const long long seg_rows = 1ll << R.seg_shift;
     if (src_dtype == R.dtype && R.ld == R.d) {
         // rows are bit-identical to the source: plain copies, one per segment touched
@@ -350,7 +353,7 @@ int ssmi_index_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int m
     if (n < 0) return fail("negative n");
     if (n == 0) return 0;
     if (!x) return fail("NULL vectors");
-    if (src_dtype != SSMI_F32 && src_dtype != SSMI_F16) return fail("unknown source dtype %d", src_dtype);
+    if (!dtype_known(src_dtype)) return fail("unknown source dtype %d", src_dtype);
     if (mem_kind != SSMI_HOST && mem_kind != SSMI_DEVICE) return fail("unknown mem_kind %d", mem_kind);
     DeviceGuard g(h->device);
     quiesce(h);
@@ -390,12 +393,12 @@ int ssmi_index_train(ssmi_index* h, int64_t n, const float* x, int mem_kind) {
 }
 
 // ------------------------------------------------------------------ search
-// Smallest query batch that takes the MFMA path.  fp16 rows: 5 (the register-FMA scan is VALU-bound beyond 4
+// Smallest query batch that takes the MFMA path.  fp16 / bf16 rows: 5 (the register-FMA scan is VALU-bound beyond 4
 // queries, the 128-query MFMA stream is HBM-bound); fp32 rows: 9 (below that the exact fp32 scan, above it the
 // fp16 shadow copy).
 static int mfma_min_batch(int dtype) {
     const char* e = getenv("SSMI_MFMA_MIN_B");
-    int v = e ? atoi(e) : (dtype == SSMI_F16 ? 5 : 9);
+    int v = e ? atoi(e) : (dtype_is16(dtype) ? 5 : 9);
     return v < 1 ? 1 : v;
 }
 
@@ -440,18 +443,40 @@ namespace ssmi {
 // record = false: no events/timing (used for the IVF coarse quantizer).
 int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev /*(nq,ld)*/, int k, float* Ddev,
                  int64_t* Idev, int64_t id_offset, hipStream_t s, bool record, ProbePlanRequest* plan, unsigned min_ord) {
-    if (R.dtype == SSMI_F16 && (R.ld % 64) == 0 && nq >= mfma_min_batch(SSMI_F16))
+    if (dtype_is16(R.dtype) && (R.ld % 64) == 0 && nq >= mfma_min_batch(R.dtype))
         return store_search_mfma(h, R, nq, qdev, k, Ddev, Idev, id_offset, s, record, min_ord);
     if (&R == &h->rows && h->kind == SSMI_KIND_FLAT && R.dtype == SSMI_F32 && (R.ld % 64) == 0 &&
         nq >= mfma_min_batch(SSMI_F32) && h->shadow_policy != 0 && !h->shadow_failed && !getenv("SSMI_NO_SHADOW")) {
-        // bring the fp16 shadow up to date, then run the MFMA contraction on it.  A shadow that does not fit in
+        // bring the 16-bit shadow up to date, then run the MFMA contraction on it.  A shadow that does not fit in
         // HBM is not an error of the search: it is dropped and this and later batches stay on the exact scan.
+        // Its element type (shadow_pref, env SSMI_SHADOW_DTYPE=f16|bf16|auto): auto = bf16 as long as every row
+        // survives the narrowing bit for bit - the reference's embeddings are bf16 model outputs cast to fp32
+        // (core/model_wrapper.py:201-203), for which a bf16 shadow is LOSSLESS and the batched search returns the
+        // exact scan's ids - and fp16 (11 significant bits against 8) as soon as one row does not: the shadow is
+        // then converted afresh from the fp32 rows, once.
         auto bring_up = [&]() -> int {
-            if (!h->has_shadow) { CHECK(h->shadow16.init(R.d, SSMI_F16, s)); h->has_shadow = true; }
+            if (!h->has_shadow) {
+                CHECK(h->shadow16.init(R.d, h->shadow_pref == SSMI_F16 ? SSMI_F16 : SSMI_BF16, s));
+                h->has_shadow = true;
+            }
             RowStore& S = h->shadow16;
             if (S.nrows < R.nrows) {
                 CHECK(S.reserve(R.nrows, s));
-                HIPCHECK(launch_shadow_rows(R.view(), (void* const*)S.d_segs, S.seg_shift, S.nrows, R.nrows - S.nrows, s));
+                const bool probe = h->shadow_pref < 0 && S.dtype == SSMI_BF16;
+                if (probe) HIPCHECK(hipMemsetAsync(h->d_flag, 0, 4, s));
+                HIPCHECK(launch_shadow_rows(R.view(), (void* const*)S.d_segs, S.seg_shift, S.dtype, S.nrows, R.nrows - S.nrows,
+                                            probe ? h->d_flag : nullptr, s));
+                int lossy = 0;
+                if (probe) {
+                    HIPCHECK(hipMemcpyAsync(&lossy, h->d_flag, 4, hipMemcpyDeviceToHost, s));
+                    HIPCHECK(hipStreamSynchronize(s));
+                }
+                if (lossy) {  // not bf16-valued after all: the shadow becomes fp16, from row 0
+                    S.destroy();
+                    CHECK(S.init(R.d, SSMI_F16, s));
+                    CHECK(S.reserve(R.nrows, s));
+                    HIPCHECK(launch_shadow_rows(R.view(), (void* const*)S.d_segs, S.seg_shift, SSMI_F16, 0, R.nrows, nullptr, s));
+                }
                 S.nrows = R.nrows;
             }
             return 0;
@@ -499,8 +524,7 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
         if (getenv("SSMI_SCAN_STAMP_SWAP")) p.tail.id_offset |= 1ll << 62;
 #endif
         if (rec) HIPCHECK(hipEventRecord(ev[0], s));
-        if (R.dtype == SSMI_F32) HIPCHECK(launch_flat_scan_f32(R.view(), qb, (int)nb, k, partial, p, s));
-        else HIPCHECK(launch_flat_scan_f16(R.view(), qb, (int)nb, k, partial, p, s));
+        HIPCHECK(launch_flat_scan(R.dtype, R.view(), qb, (int)nb, k, partial, p, s));
         if (rec) HIPCHECK(hipEventRecord(ev[1], s));
 #ifdef SSMI_SCAN_STAMP
         if (getenv("SSMI_SCAN_STAMP_PRINT") && record) {  // finish time of the rows per XCD (block b runs on XCD b % 8)
@@ -808,6 +832,12 @@ int ssmi_index_get_shadow_state(const ssmi_index* h, int* policy, int64_t* shado
     *policy = h->shadow_policy;
     *shadow_rows = h->has_shadow ? h->shadow16.nrows : 0;
     *failed = h->shadow_failed ? 1 : 0;
+    return 0;
+}
+
+int ssmi_index_get_shadow_dtype(const ssmi_index* h, int* out) {
+    if (!h || !out) return fail("NULL argument");
+    *out = h->has_shadow ? h->shadow16.dtype : -1;
     return 0;
 }
 

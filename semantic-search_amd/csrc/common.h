@@ -37,6 +37,35 @@ __host__ __device__ inline uint32_t key_id(skey_t k) { return 0xFFFFFFFFu - (uin
 
 #define SSMI_NEG_MAX (-3.402823466e+38f)
 
+// element types of the row stores (include/ssmi.h: SSMI_F32 / SSMI_F16 / SSMI_BF16)
+__host__ __device__ inline int dtype_elsize(int dtype) { return dtype == 0 ? 4 : 2; }
+__host__ __device__ inline bool dtype_is16(int dtype) { return dtype == 1 || dtype == 2; }
+__host__ __device__ inline bool dtype_known(int dtype) { return dtype >= 0 && dtype <= 2; }
+
+// bfloat16 storage element: the upper half of an fp32.  Widening is a shift (exact), narrowing rounds to nearest
+// even (NaN stays NaN); no arithmetic is ever done in this type.
+struct bf16_t {
+    uint16_t x;
+    bf16_t() = default;
+    __host__ __device__ explicit bf16_t(float f) {
+#ifdef __HIP_DEVICE_COMPILE__
+        uint32_t u = __float_as_uint(f);
+#else
+        union { float f; uint32_t u; } c; c.f = f; uint32_t u = c.u;
+#endif
+        if ((u & 0x7fffffffu) > 0x7f800000u) x = (uint16_t)((u >> 16) | 0x0040u);
+        else x = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+    __host__ __device__ operator float() const {
+#ifdef __HIP_DEVICE_COMPILE__
+        return __uint_as_float((uint32_t)x << 16);
+#else
+        union { float f; uint32_t u; } c; c.u = (uint32_t)x << 16; return c.f;
+#endif
+    }
+};
+static_assert(sizeof(bf16_t) == 2, "bf16_t is a 16-bit storage element");
+
 // Row store handed to kernels: a table of equally sized segments.
 struct RowView {
     const void* const* segs;  // device table of segment base pointers

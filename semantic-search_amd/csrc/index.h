@@ -46,6 +46,10 @@ struct ssmi_index {
     // exact fp32 scan).  ssmi_index_set_shadow_policy; env SSMI_NO_SHADOW=1 overrides to 0.
     int shadow_policy = 1;
     bool shadow_failed = false;  // the shadow did not fit in HBM: searches fell back to the exact scan (reset by add)
+    // element type of the shadow: SSMI_F16, SSMI_BF16, or -1 = auto (bf16 while every row is bf16-valued, i.e. the
+    // shadow is lossless; fp16 otherwise).  env SSMI_SHADOW_DTYPE=f16|bf16|auto
+    int shadow_pref = -1;
+    int* d_flag = nullptr;       // 256 bytes of device scratch for one-word answers (the shadow's "lossy" flag)
     hipStream_t stream = nullptr;
     // Searches with device buffers return after ENQUEUEING on the caller's stream, while the workspaces, the IVF
     // page tables and the ticket counters belong to the handle.  The handle therefore remembers the stream of

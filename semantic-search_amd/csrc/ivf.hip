@@ -547,7 +547,7 @@ int rows_to_device_f32(ssmi_index* h, int64_t n, const void* x, int src_dtype, i
         *out = dst;
         return 0;
     }
-    const size_t el = src_dtype == SSMI_F32 ? 4 : 2;
+    const size_t el = (size_t)dtype_elsize(src_dtype);
     const void* src = x;
     if (mem_kind == SSMI_HOST) {
         CHECK(ensure_ws(h, 0, (size_t)n * R.d * el));
@@ -556,8 +556,10 @@ int rows_to_device_f32(ssmi_index* h, int64_t n, const void* x, int src_dtype, i
     }
     if (src_dtype == SSMI_F32)
         hipLaunchKernelGGL((rows_to_f32_kernel<float>), dim3((unsigned)n), dim3(256), 0, h->stream, (const float*)src, R.d, R.ld, dst);
-    else
+    else if (src_dtype == SSMI_F16)
         hipLaunchKernelGGL((rows_to_f32_kernel<__half>), dim3((unsigned)n), dim3(256), 0, h->stream, (const __half*)src, R.d, R.ld, dst);
+    else
+        hipLaunchKernelGGL((rows_to_f32_kernel<bf16_t>), dim3((unsigned)n), dim3(256), 0, h->stream, (const bf16_t*)src, R.d, R.ld, dst);
     HIPCHECK(hipGetLastError());
     *out = dst;
     return 0;
@@ -867,8 +869,11 @@ static int ivf_append_labelled(ssmi_index* h, int64_t n, const float* xdev, cons
         if (R.dtype == SSMI_F32)
             hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)d_slot,
                                (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, id0, ids_dev);
-        else
+        else if (R.dtype == SSMI_F16)
             hipLaunchKernelGGL((scatter_rows_kernel<__half>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)d_slot,
+                               (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, id0, ids_dev);
+        else
+            hipLaunchKernelGGL((scatter_rows_kernel<bf16_t>), dim3((unsigned)n), dim3(256), 0, h->stream, xdev, R.ld, (const int*)d_slot,
                                (void* const*)R.d_segs, R.seg_shift, S->d_slot_ids, id0, ids_dev);
         HIPCHECK(hipGetLastError());
         if (h->has_shadow && R.dtype == SSMI_F32) {
@@ -927,7 +932,7 @@ int ivf_add_shard(ssmi_index* h, int64_t n, const void* x, int src_dtype, int me
     if (id0 < 0 || (unsigned long long)(id0 + n) >= 0xFFFFFFFFull) return fail("ids would exceed 2^32-2");
     if (st(h)->has_direct_map) return fail("a list-sharded index cannot maintain a direct map");
     const RowStore& R = h->rows;
-    const size_t el = src_dtype == SSMI_F32 ? 4 : 2;
+    const size_t el = (size_t)dtype_elsize(src_dtype);
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(1 << 16, ((size_t)1 << 30) / ((size_t)R.ld * 4)));
     for (int64_t done = 0; done < n; done += chunk) {
         const int64_t cnt = std::min(chunk, n - done);
@@ -947,7 +952,7 @@ int ivf_add(ssmi_index* h, int64_t n, const void* x, int src_dtype, int mem_kind
     if (!h->trained) return fail("add on an untrained IVF index (call train first)");
     if ((unsigned long long)(h->ivf_ntotal + n) >= 0xFFFFFFFFull) return fail("index would exceed 2^32-2 vectors");
     const RowStore& R = h->rows;
-    const size_t el = src_dtype == SSMI_F32 ? 4 : 2;
+    const size_t el = (size_t)dtype_elsize(src_dtype);
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(1 << 16, ((size_t)1 << 30) / ((size_t)R.ld * 4)));
     for (int64_t done = 0; done < n; done += chunk) {
         const int64_t cnt = std::min(chunk, n - done);
@@ -1039,7 +1044,7 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
     int lbt = 0, lthreads = 0;
     size_t llds = 0;
     const char* env_lm = getenv("SSMI_IVF_LISTMAJOR");  // tests: 0 = never, 1 = always (when it fits)
-    const double per_query_bytes = (double)nq * nprobe / h->nlist * (double)R.nrows * R.ld * (R.dtype == SSMI_F32 ? 4 : 2);
+    const double per_query_bytes = (double)nq * nprobe / h->nlist * (double)R.nrows * R.ld * dtype_elsize(R.dtype);
     bool list_major = nq >= 16 && (nq * (int64_t)nprobe >= 2 * (int64_t)h->nlist ||
                                    (3 * nq * (int64_t)nprobe >= (int64_t)h->nlist && per_query_bytes >= 8e9));
     if (env_lm) list_major = env_lm[0] == '1';
@@ -1055,7 +1060,7 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
             h->has_shadow = true;
             CHECK(h->shadow16.reserve(R.nrows, s));
             RowView src = R.view();
-            HIPCHECK(launch_shadow_rows(src, (void* const*)h->shadow16.d_segs, h->shadow16.seg_shift, 0, R.nrows, s));
+            HIPCHECK(launch_shadow_rows(src, (void* const*)h->shadow16.d_segs, h->shadow16.seg_shift, SSMI_F16, 0, R.nrows, nullptr, s));
             h->shadow16.nrows = R.nrows;
             return 0;
         };
@@ -1097,13 +1102,14 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
                 if (via_shadow) A.X = h->shadow16.view();
                 CHECK(ensure_ws(h, 4, (size_t)nb * R.ld * 2));
                 CHECK(ensure_ws(h, 5, ivf_list_mfma_cand_bytes(h->num_cu)));
-                HIPCHECK(launch_cvt_queries_f16(qb, nb, nb, R.ld, h->ws[4], s));
+                const bool lists_bf16 = !via_shadow && R.dtype == SSMI_BF16;  // (the shadow of fp32 lists is always fp16)
+                HIPCHECK(launch_cvt_queries_16(qb, nb, nb, R.ld, h->ws[4], lists_bf16, s));
                 if (!getenv("SSMI_IVF_LIST_SHARE_THR") || getenv("SSMI_IVF_LIST_SHARE_THR")[0] != '0') {
                     A.qthr = (unsigned*)(A.uoff + h->nlist + 1);  // behind the four tables of workspace 11
                     HIPCHECK(hipMemsetAsync(A.qthr, 0, (size_t)nb * 4, s));
                 }
                 if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[0], s));
-                HIPCHECK(launch_ivf_list_scan_mfma(A, h->ws[4], h->ws[5], h->num_cu, s));
+                HIPCHECK(launch_ivf_list_scan_mfma(A, h->ws[4], h->ws[5], h->num_cu, lists_bf16, s));
                 if (h->timing_on && done == 0) HIPCHECK(hipEventRecord(ev[1], s));
             } else {
                 A.bt = lbt; A.threads = lthreads; A.lds = llds;
@@ -1160,7 +1166,7 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
                 case 2: IVF_QLAUNCH_R(float, 2) break;
                 default: IVF_QLAUNCH_R(float, 1) break;
             }
-        } else if (qreg) {
+        } else if (qreg && R.dtype == SSMI_F16) {
             switch (row_kib) {
                 case 16: IVF_QLAUNCH_R(__half, 16) break;
                 case 8: IVF_QLAUNCH_R(__half, 8) break;
@@ -1168,10 +1174,20 @@ int ivf_search(ssmi_index* h, int64_t nq, const float* qdev, int k, float* Ddev,
                 case 2: IVF_QLAUNCH_R(__half, 2) break;
                 default: IVF_QLAUNCH_R(__half, 1) break;
             }
+        } else if (qreg) {
+            switch (row_kib) {
+                case 16: IVF_QLAUNCH_R(bf16_t, 16) break;
+                case 8: IVF_QLAUNCH_R(bf16_t, 8) break;
+                case 4: IVF_QLAUNCH_R(bf16_t, 4) break;
+                case 2: IVF_QLAUNCH_R(bf16_t, 2) break;
+                default: IVF_QLAUNCH_R(bf16_t, 1) break;
+            }
         } else if (R.dtype == SSMI_F32) {
             switch (r) { IVF_LAUNCH(float, 1) IVF_LAUNCH(float, 2) IVF_LAUNCH(float, 4) IVF_LAUNCH(float, 8) IVF_LAUNCH(float, 16) default: return fail("bad k"); }
-        } else {
+        } else if (R.dtype == SSMI_F16) {
             switch (r) { IVF_LAUNCH(__half, 1) IVF_LAUNCH(__half, 2) IVF_LAUNCH(__half, 4) IVF_LAUNCH(__half, 8) IVF_LAUNCH(__half, 16) default: return fail("bad k"); }
+        } else {
+            switch (r) { IVF_LAUNCH(bf16_t, 1) IVF_LAUNCH(bf16_t, 2) IVF_LAUNCH(bf16_t, 4) IVF_LAUNCH(bf16_t, 8) IVF_LAUNCH(bf16_t, 16) default: return fail("bad k"); }
         }
 #undef IVF_LAUNCH
 #undef IVF_QLAUNCH
@@ -1334,7 +1350,7 @@ int ssmi_index_add_ivf_shard(ssmi_index* h, int64_t n, const void* x, int src_dt
     if (n < 0) return fail("negative n");
     if (n == 0) return 0;
     if (!x) return fail("NULL vectors");
-    if (src_dtype != SSMI_F32 && src_dtype != SSMI_F16) return fail("unknown source dtype %d", src_dtype);
+    if (!dtype_known(src_dtype)) return fail("unknown source dtype %d", src_dtype);
     if (mem_kind != SSMI_HOST && mem_kind != SSMI_DEVICE) return fail("unknown mem_kind %d", mem_kind);
     DeviceGuard g(h->device);
     quiesce(h);
@@ -1350,12 +1366,12 @@ int ssmi_index_assign(ssmi_index* h, int64_t n, const void* x, int src_dtype, in
     if (n < 0) return fail("negative n");
     if (n == 0) return 0;
     if (!x || !labels_out_host) return fail("NULL buffer");
-    if (src_dtype != SSMI_F32 && src_dtype != SSMI_F16) return fail("unknown source dtype %d", src_dtype);
+    if (!dtype_known(src_dtype)) return fail("unknown source dtype %d", src_dtype);
     if (mem_kind != SSMI_HOST && mem_kind != SSMI_DEVICE) return fail("unknown mem_kind %d", mem_kind);
     DeviceGuard g(h->device);
     quiesce(h);
     const RowStore& R = h->rows;
-    const size_t el = src_dtype == SSMI_F32 ? 4 : 2;
+    const size_t el = (size_t)dtype_elsize(src_dtype);
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(1 << 16, ((size_t)1 << 30) / ((size_t)R.ld * 4)));
     std::vector<int> labels;
     for (int64_t done = 0; done < n; done += chunk) {
@@ -1378,7 +1394,7 @@ int ssmi_index_add_preassigned(ssmi_index* h, int64_t n, const void* x, int src_
     if (n < 0) return fail("negative n");
     if (n == 0) return 0;
     if (!x || !labels_host || !ids_host) return fail("NULL buffer");
-    if (src_dtype != SSMI_F32 && src_dtype != SSMI_F16) return fail("unknown source dtype %d", src_dtype);
+    if (!dtype_known(src_dtype)) return fail("unknown source dtype %d", src_dtype);
     if (mem_kind != SSMI_HOST && mem_kind != SSMI_DEVICE) return fail("unknown mem_kind %d", mem_kind);
     if (st(h)->has_direct_map) return fail("an index filled with explicit ids cannot maintain a direct map");
     std::vector<uint32_t> ids32((size_t)n);
@@ -1392,7 +1408,7 @@ int ssmi_index_add_preassigned(ssmi_index* h, int64_t n, const void* x, int src_
     DeviceGuard g(h->device);
     quiesce(h);
     const RowStore& R = h->rows;
-    const size_t el = src_dtype == SSMI_F32 ? 4 : 2;
+    const size_t el = (size_t)dtype_elsize(src_dtype);
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(1 << 16, ((size_t)1 << 30) / ((size_t)R.ld * 4)));
     for (int64_t done = 0; done < n; done += chunk) {
         const int64_t cnt = std::min(chunk, n - done);

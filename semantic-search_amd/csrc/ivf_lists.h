@@ -32,11 +32,12 @@ bool plan_ivf_list_scan(int dtype, int ld, int k, int* bt, int* threads, size_t*
 hipError_t launch_ivf_probe_table(const IvfListScanArgs& A, hipStream_t s);
 hipError_t launch_ivf_list_scan(const IvfListScanArgs& A, int dtype, hipStream_t s);
 
-// MFMA form (ivf_lists_mfma.hip): fp16 lists, rows of a multiple of 512 elements, k <= 256
+// MFMA form (ivf_lists_mfma.hip): fp16 or bf16 lists, rows of a multiple of 512 elements, k <= 256
 bool ivf_list_mfma_supported(int dtype, int ld, int k);
 int ivf_list_mfma_bt(long long nq, int nprobe, int nlist);  // queries per work item: 16, 64 or 128
 size_t ivf_list_mfma_cand_bytes(int num_cu);
-// A.bt from ivf_list_mfma_bt; qh: (nq, ld) fp16 queries; cand: ivf_list_mfma_cand_bytes workspace
-hipError_t launch_ivf_list_scan_mfma(const IvfListScanArgs& A, const void* qh, void* cand, int num_cu, hipStream_t s);
+// A.bt from ivf_list_mfma_bt; qh: (nq, ld) queries narrowed to the lists' 16-bit format (bf16 says which); cand:
+// ivf_list_mfma_cand_bytes workspace
+hipError_t launch_ivf_list_scan_mfma(const IvfListScanArgs& A, const void* qh, void* cand, int num_cu, bool bf16, hipStream_t s);
 
 }  // namespace ssmi

@@ -248,7 +248,7 @@ hipError_t launch_ivf_probe_table(const IvfListScanArgs& A, hipStream_t s) {
 hipError_t launch_ivf_list_scan(const IvfListScanArgs& A, int dtype, hipStream_t s) {
     hipError_t e = launch_ivf_probe_table(A, s);
     if (e != hipSuccess) return e;
-    return dtype == 0 ? launch_t<float>(A, s) : launch_t<__half>(A, s);
+    return dtype == 0 ? launch_t<float>(A, s) : (dtype == 1 ? launch_t<__half>(A, s) : launch_t<bf16_t>(A, s));
 }
 
 }  // namespace ssmi

@@ -36,7 +36,7 @@ __device__ __forceinline__ const unsigned char* sload_ptr(const void* const* p) 
     return v;
 }
 
-template <int R, int PD, int NT>
+template <int R, int PD, int NT, bool BF = false>
 __global__ void __launch_bounds__(512) ivf_scan_lists_mfma_kernel(IvfListScanArgs A, const _Float16* __restrict__ Qh,
                                                                   skey_t* __restrict__ cand_all, int* __restrict__ work_counter) {
     constexpr int QD = PD + 1;
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(512) ivf_scan_lists_mfma_kernel(IvfListScanArg
                             for (int m = 0; m < 2; ++m)
 #pragma unroll
                                 for (int n = 0; n < NT; ++n)
-                                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(areg[u][m][kh], b[n], acc[m][n], 0, 0, 0);
+                                    acc[m][n] = mfma16<BF>(areg[u][m][kh], b[n], acc[m][n]);
                         }
                         {   // refill ring slot u with step g + PD (next tile's page when this one is used up; past the
                             // end of the list: this step again, never consumed)
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(512) ivf_scan_lists_mfma_kernel(IvfListScanArg
     }
 }
 
-bool ivf_list_mfma_supported(int dtype, int ld, int k) { return dtype == 1 && (ld % 512) == 0 && k <= 256; }
+bool ivf_list_mfma_supported(int dtype, int ld, int k) { return dtype_is16(dtype) && (ld % 512) == 0 && k <= 256; }
 
 // queries per work item for this batch: the smallest of 16 / 64 / 128 that covers twice the average probes per list
 int ivf_list_mfma_bt(long long nq, int nprobe, int nlist) {
@@ -271,27 +271,28 @@ size_t ivf_list_mfma_cand_bytes(int num_cu) { return (size_t)num_cu * N128_TN * 
 
 template <int PD, int NT>
 static hipError_t launch_nt(const IvfListScanArgs& A, const _Float16* Qh, skey_t* cand, int* counter, int r, int grid,
-                            hipStream_t s) {
+                            bool bf16, hipStream_t s) {
     const size_t lds = (size_t)(PD + 1) * LQ_SLOT + 3 * N128_TN * 4 + 32;
     hipError_t e;
-#define LAUNCH_R(RR)                                                                                         \
-    case RR: {                                                                                               \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_scan_lists_mfma_kernel<RR, PD, NT>),      \
+#define LAUNCH_K(...)                                                                                        \
+    {                                                                                                        \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_scan_lists_mfma_kernel<__VA_ARGS__>),     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
         if (e != hipSuccess) return e;                                                                       \
-        hipLaunchKernelGGL((ivf_scan_lists_mfma_kernel<RR, PD, NT>), dim3(grid), dim3(512), lds, s, A, Qh, cand, counter); \
-        break;                                                                                               \
+        hipLaunchKernelGGL((ivf_scan_lists_mfma_kernel<__VA_ARGS__>), dim3(grid), dim3(512), lds, s, A, Qh, cand, counter); \
     }
+#define LAUNCH_R(RR) case RR: if (bf16) LAUNCH_K(RR, PD, NT, true) else LAUNCH_K(RR, PD, NT, false) break;
     switch (r) {
         LAUNCH_R(1) LAUNCH_R(2) LAUNCH_R(4)
         default: return hipErrorInvalidValue;
     }
 #undef LAUNCH_R
+#undef LAUNCH_K
     return hipGetLastError();
 }
 
 // A.bt must be 16, 64 or 128; A.cnt has 2*nlist+1 ints (the last one is the work counter); grid = one block per CU.
-hipError_t launch_ivf_list_scan_mfma(const IvfListScanArgs& A, const void* qh, void* cand, int num_cu, hipStream_t s) {
+hipError_t launch_ivf_list_scan_mfma(const IvfListScanArgs& A, const void* qh, void* cand, int num_cu, bool bf16, hipStream_t s) {
     const long long n_entries = (long long)A.nq * A.nprobe;
     hipError_t e = launch_ivf_probe_table(A, s);
     if (e != hipSuccess) return e;
@@ -300,9 +301,9 @@ hipError_t launch_ivf_list_scan_mfma(const IvfListScanArgs& A, const void* qh, v
     while (64 * r < A.k) r <<= 1;
     int* counter = A.cnt + 2 * A.nlist;
     const _Float16* Qh = (const _Float16*)qh;
-    if (A.bt == 16) return launch_nt<8, 1>(A, Qh, (skey_t*)cand, counter, r, num_cu, s);
-    if (A.bt == 64) return launch_nt<8, 4>(A, Qh, (skey_t*)cand, counter, r, num_cu, s);
-    return launch_nt<4, 8>(A, Qh, (skey_t*)cand, counter, r, num_cu, s);
+    if (A.bt == 16) return launch_nt<8, 1>(A, Qh, (skey_t*)cand, counter, r, num_cu, bf16, s);
+    if (A.bt == 64) return launch_nt<8, 4>(A, Qh, (skey_t*)cand, counter, r, num_cu, bf16, s);
+    return launch_nt<4, 8>(A, Qh, (skey_t*)cand, counter, r, num_cu, bf16, s);
 }
 
 }  // namespace ssmi

@@ -22,14 +22,20 @@ struct ScanPlan {
 bool plan_flat_scan(int dtype, int ld, long long nrows, int nq, int k, int num_cu, ScanPlan* p, std::string* err);
 hipError_t launch_flat_scan_f32(const RowView& X, const float* Q, int nq, int k, skey_t* partial, const ScanPlan& p, hipStream_t s);
 hipError_t launch_flat_scan_f16(const RowView& X, const float* Q, int nq, int k, skey_t* partial, const ScanPlan& p, hipStream_t s);
+hipError_t launch_flat_scan_bf16(const RowView& X, const float* Q, int nq, int k, skey_t* partial, const ScanPlan& p, hipStream_t s);
+inline hipError_t launch_flat_scan(int dtype, const RowView& X, const float* Q, int nq, int k, skey_t* partial, const ScanPlan& p, hipStream_t s) {
+    return dtype == 0 ? launch_flat_scan_f32(X, Q, nq, k, partial, p, s)
+         : dtype == 1 ? launch_flat_scan_f16(X, Q, nq, k, partial, p, s) : launch_flat_scan_bf16(X, Q, nq, k, partial, p, s);
+}
 
-// K2 planning + launch (fp16 storage, ld % 64 == 0)
+// K2 planning + launch (fp16 or bf16 storage, ld % 64 == 0)
 struct MfmaPlan {
     int nqt, nslices, grid;
     int gtop_m;   // scores every slice publishes per query for the cross-slice threshold bound (0: none)
     bool narrow;  // <= 128 queries: the HBM-bound 128-query-tile stream (mfma_n128.hip)
     long long rows_per_slice;
-    int q_pitch;  // halves per row of the fp16 query workspace (ld, or ld + 64 for the 256-query kernel)
+    int q_pitch;  // halves per row of the 16-bit query workspace (ld, or ld + 64 for the 256-query kernel)
+    int dtype;    // SSMI_F16 or SSMI_BF16: the rows' type; queries are narrowed to the same type
     size_t qh_bytes, cand_bytes, lds;
     const char* kernel;  // which contraction kernel launch_flat_mfma will run
 };
@@ -38,8 +44,8 @@ bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_c
 hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, const MfmaPlan& p, void* qh, void* cand,
                             skey_t* partial, hipStream_t s, unsigned min_ord = 0);
 
-// (nq, ld) fp32 queries -> (rows_out >= nq, ld) fp16, zero rows beyond nq
-hipError_t launch_cvt_queries_f16(const float* q, int nq, int rows_out, int ld, void* out, hipStream_t s);
+// (nq, ld) fp32 queries -> (rows_out >= nq, ld) fp16 (bf16 = false) or bf16, zero rows beyond nq
+hipError_t launch_cvt_queries_16(const float* q, int nq, int rows_out, int ld, void* out, bool bf16, hipStream_t s);
 
 // K3: merge P sorted k-lists of keys per query -> (D, I)
 hipError_t launch_merge_keys(const skey_t* partial, int nq, int P, int k, float* D, int64_t* I,
@@ -60,8 +66,10 @@ hipError_t launch_score_rows(const RowView& X, int dtype, const int64_t* ids, lo
 // K10: append unit-norm gaussian rows [row0,row0+n)
 hipError_t launch_fill_random_unit(const RowView& X, int dtype, void* const* segs_rw, long long row0, long long n,
                                    int d, uint64_t seed, hipStream_t s);
-// fp32 store rows -> fp16 shadow store rows
-hipError_t launch_shadow_rows(const RowView& src, void* const* dsegs, int dshift, long long row0, long long n, hipStream_t s);
+// fp32 store rows -> 16-bit shadow store rows (dst_dtype 1 = fp16, 2 = bf16); *inexact (device int, may be null) is
+// set when some value does not survive the narrowing exactly
+hipError_t launch_shadow_rows(const RowView& src, void* const* dsegs, int dshift, int dst_dtype, long long row0, long long n,
+                              int* inexact, hipStream_t s);
 // fill (nq,k) outputs with the "no result" padding
 hipError_t launch_fill_empty(float* D, int64_t* I, long long n, hipStream_t s);
 // pad queries (nq,d) -> (nq,ld) fp32 (zero tail)

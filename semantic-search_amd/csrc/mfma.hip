@@ -36,32 +36,37 @@ namespace ssmi {
 // pitch == ld: plain rows.  pitch == ld + 64 (the 256-query kernel, mfma_pp.hip): a row is [32 halves of zeros][ld
 // values][the first 32 values again], so that the 128-byte pieces of the query stream that start at an ODD 32-deep
 // phase are whole cache lines and the piece behind the last phase holds the first phase of the next row tile.
-__global__ void cvt_queries_f16_kernel(const float* __restrict__ q, int nq, int ld, _Float16* __restrict__ out,
-                                       unsigned* __restrict__ gthr, unsigned* __restrict__ gtop, int gtop_words, int pitch) {
+// H: _Float16 or bf16_t (round to nearest even either way) - the operand type of the rows the batch will meet.
+template <typename H>
+__global__ void cvt_queries_16_kernel(const float* __restrict__ q, int nq, int ld, H* __restrict__ out,
+                                      unsigned* __restrict__ gthr, unsigned* __restrict__ gtop, int gtop_words, int pitch) {
     const int i = blockIdx.x;  // padded row
     if (gthr && threadIdx.x == 0) gthr[i] = 0;
     if (gtop)
         for (int e = threadIdx.x; e < gtop_words; e += blockDim.x) gtop[(size_t)i * gtop_words + e] = 0;
     const int off = (pitch - ld) / 2;
     for (int e = threadIdx.x; e < ld; e += blockDim.x)
-        out[(size_t)i * pitch + off + e] = (i < nq) ? (_Float16)q[(size_t)i * ld + e] : (_Float16)0.f;
+        out[(size_t)i * pitch + off + e] = (i < nq) ? (H)q[(size_t)i * ld + e] : (H)0.f;
     if (off) {
         for (int e = threadIdx.x; e < off; e += blockDim.x) {
-            out[(size_t)i * pitch + e] = (_Float16)0.f;
-            out[(size_t)i * pitch + off + ld + e] = (i < nq) ? (_Float16)q[(size_t)i * ld + e] : (_Float16)0.f;
+            out[(size_t)i * pitch + e] = (H)0.f;
+            out[(size_t)i * pitch + off + ld + e] = (i < nq) ? (H)q[(size_t)i * ld + e] : (H)0.f;
         }
     }
 }
 
-// (nq, ld) fp32 -> (rows_out, ld) fp16, zero rows beyond nq
-hipError_t launch_cvt_queries_f16(const float* q, int nq, int rows_out, int ld, void* out, hipStream_t s) {
-    hipLaunchKernelGGL(cvt_queries_f16_kernel, dim3(rows_out), dim3(256), 0, s, q, nq, ld, (_Float16*)out, (unsigned*)nullptr,
-                       (unsigned*)nullptr, 0, ld);
+// (nq, ld) fp32 -> (rows_out, ld) fp16 / bf16, zero rows beyond nq
+hipError_t launch_cvt_queries_16(const float* q, int nq, int rows_out, int ld, void* out, bool bf16, hipStream_t s) {
+    if (bf16) hipLaunchKernelGGL(cvt_queries_16_kernel<bf16_t>, dim3(rows_out), dim3(256), 0, s, q, nq, ld, (bf16_t*)out, (unsigned*)nullptr,
+                                 (unsigned*)nullptr, 0, ld);
+    else hipLaunchKernelGGL(cvt_queries_16_kernel<_Float16>, dim3(rows_out), dim3(256), 0, s, q, nq, ld, (_Float16*)out, (unsigned*)nullptr,
+                            (unsigned*)nullptr, 0, ld);
     return hipGetLastError();
 }
 
 bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_cu, MfmaPlan* p) {
-    if (dtype != 1 || (ld % BK) != 0 || nrows < 1 || nq < 1 || k < 1 || k > kMaxK) return false;
+    if (!dtype_is16(dtype) || (ld % BK) != 0 || nrows < 1 || nq < 1 || k < 1 || k > kMaxK) return false;
+    p->dtype = dtype;
     p->nqt = (nq + TN - 1) / TN;
     const long long row_tiles = (nrows + TM - 1) / TM;
     long long ns = num_cu / p->nqt;
@@ -98,11 +103,16 @@ hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, con
     // (a batch of a few queries on the register-ring kernel gains nothing and pays for the ring drains of the exchange)
     const bool share_tops = share_thr && p.gtop_m > 0 && k > 1 && !(p.narrow && nq < 32 && k <= 16) && !(env_g && env_g[0] == '0');
     unsigned* gtop = gthr + (size_t)p.nqt * TN;
-    hipLaunchKernelGGL(cvt_queries_f16_kernel, dim3(p.nqt * TN), dim3(256), 0, s, Q, nq, X.ld, (_Float16*)qh, gthr,
-                       share_tops ? gtop : (unsigned*)nullptr, p.nslices * p.gtop_m, p.q_pitch);
+    if (p.dtype == 2)
+        hipLaunchKernelGGL(cvt_queries_16_kernel<bf16_t>, dim3(p.nqt * TN), dim3(256), 0, s, Q, nq, X.ld, (bf16_t*)qh, gthr,
+                           share_tops ? gtop : (unsigned*)nullptr, p.nslices * p.gtop_m, p.q_pitch);
+    else
+        hipLaunchKernelGGL(cvt_queries_16_kernel<_Float16>, dim3(p.nqt * TN), dim3(256), 0, s, Q, nq, X.ld, (_Float16*)qh, gthr,
+                           share_tops ? gtop : (unsigned*)nullptr, p.nslices * p.gtop_m, p.q_pitch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     MfmaParams P = {};
+    P.bf16 = p.dtype == 2;
     P.X = X; P.Qh = (const _Float16*)qh; P.q_pitch = p.q_pitch; P.nq = nq; P.k = k; P.nqt = p.nqt; P.nslices = p.nslices;
     P.rows_per_slice = p.rows_per_slice; P.partial = partial; P.cand = (skey_t*)cand;
     P.gthr = (share_thr && p.nslices > 1) ? gthr : nullptr;

@@ -7,14 +7,24 @@ namespace ssmi {
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// One 16x16x32 MFMA on 16-bit operands, fp32 accumulate.  The kernels move the operands as opaque 16-byte fragments
+// (half8_t is only the container); BF says which format the bits are in.  Same rate, same layout for both.
+template <bool BF>
+__device__ __forceinline__ f32x4_t mfma16(const half8_t& a, const half8_t& b, const f32x4_t& c) {
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 
 static constexpr int TM = 256, TN = 256, BK = 64;
 static constexpr int TILE_BYTES = TM * BK * 2;  // one operand tile: 32 KiB
 static constexpr int CAND_CAP = 512, CAND_TRIG = 256;
 
 struct MfmaParams {
-    RowView X;                 // fp16 rows, ld % 64 == 0
-    const _Float16* Qh;        // [nqt*256][q_pitch] fp16, zero rows beyond nq
+    RowView X;                 // fp16 or bf16 rows (bf16 says which), ld % 64 == 0
+    bool bf16;
+    const _Float16* Qh;        // [nqt*256][q_pitch] 16-bit queries in the rows' format, zero rows beyond nq
     int q_pitch;               // ld (128-query kernels) or ld + 64 (256-query kernel: see cvt_queries_f16_kernel)
     int nq, k, nqt, nslices;
     long long rows_per_slice;  // multiple of 256

@@ -28,7 +28,7 @@ static constexpr int NSLAB_X = 256 * 64;  // 16 KiB
 static constexpr int NSLAB_Q = 128 * 64;  // 8 KiB
 static_assert(NSLAB_X + NSLAB_Q == N128_SLOT, "slot size");
 
-template <int R>
+template <int R, bool BF = false>
 __global__ void __launch_bounds__(512) flat_mfma_n128_kernel(MfmaParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* thr_l = reinterpret_cast<float*>(smem + N128_RING * N128_SLOT);
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(512) flat_mfma_n128_kernel(MfmaParams P) {
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int n = 0; n < 4; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], b[n], acc[m][n], 0, 0, 0);
+                acc[m][n] = mfma16<BF>(a[m], b[n], acc[m][n]);
         __builtin_amdgcn_sched_barrier(0);
 
         if (++p == np) {  // row tile complete: filter its scores, maybe fold the candidate buffers
@@ -170,19 +170,20 @@ __global__ void __launch_bounds__(512) flat_mfma_n128_kernel(MfmaParams P) {
 
 hipError_t launch_flat_mfma_n128(const MfmaParams& P, int r, int grid, size_t lds, hipStream_t s) {
     hipError_t e;
-#define LAUNCH_R(RR)                                                                                    \
-    case RR: {                                                                                          \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(flat_mfma_n128_kernel<RR>),              \
+#define LAUNCH_K(...)                                                                                   \
+    {                                                                                                   \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(flat_mfma_n128_kernel<__VA_ARGS__>),     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
         if (e != hipSuccess) return e;                                                                  \
-        hipLaunchKernelGGL((flat_mfma_n128_kernel<RR>), dim3(grid), dim3(512), lds, s, P);             \
-        break;                                                                                          \
+        hipLaunchKernelGGL((flat_mfma_n128_kernel<__VA_ARGS__>), dim3(grid), dim3(512), lds, s, P);    \
     }
+#define LAUNCH_R(RR) case RR: if (P.bf16) LAUNCH_K(RR, true) else LAUNCH_K(RR, false) break;
     switch (r) {
         LAUNCH_R(1) LAUNCH_R(2) LAUNCH_R(4) LAUNCH_R(8) LAUNCH_R(16)
         default: return hipErrorInvalidValue;
     }
 #undef LAUNCH_R
+#undef LAUNCH_K
     return hipGetLastError();
 }
 

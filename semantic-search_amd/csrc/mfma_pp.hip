@@ -67,7 +67,8 @@ static constexpr int QRING = RING * SLAB;      // offset of the Q slabs
 // the best (score, row) of each of its four query columns across the row tiles of the slice, the four lanes and two
 // waves that share a column combine once at the end.  Assignment batches have no score structure to prune with
 // (every centroid scores alike on unclustered rows), so the filter path spent its time on survivors there.
-template <int R, bool ARGMAX = false>
+// BF: the operands are bf16 (v_mfma_f32_16x16x32_bf16), else fp16; nothing else differs.
+template <int R, bool ARGMAX = false, bool BF = false>
 __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* thr_l = reinterpret_cast<float*>(smem + RING * PHASE_LDS);
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
             for (int m = 0; m < 8; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], b[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = mfma16<BF>(a[m], b[n], acc[m][n]);
 #if SSMI_PP_PRIO == 0
             __builtin_amdgcn_s_setprio(0);
 #endif
@@ -383,25 +384,23 @@ hipError_t launch_flat_mfma_pp(const MfmaParams& P_in, int r, int grid, size_t l
     if (!dbg) (void)hipMalloc((void**)&dbg, 4096 * 8 * 8 * 8);
     P.dbg = dbg;
 #endif
-#define LAUNCH_R(RR)                                                                                    \
-    case RR: {                                                                                          \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(flat_mfma_pp_kernel<RR>),                \
+#define LAUNCH_K(...)                                                                                   \
+    {                                                                                                   \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(flat_mfma_pp_kernel<__VA_ARGS__>),       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
         if (e != hipSuccess) return e;                                                                  \
-        hipLaunchKernelGGL((flat_mfma_pp_kernel<RR>), dim3(grid), dim3(512), lds, s, P);               \
-        break;                                                                                          \
+        hipLaunchKernelGGL((flat_mfma_pp_kernel<__VA_ARGS__>), dim3(grid), dim3(512), lds, s, P);      \
     }
+#define LAUNCH_R(RR) case RR: if (P.bf16) LAUNCH_K(RR, false, true) else LAUNCH_K(RR, false, false) break;
     if (P.k == 1) {  // nearest-centroid assignment and any other top-1 batch
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(flat_mfma_pp_kernel<1, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((flat_mfma_pp_kernel<1, true>), dim3(grid), dim3(512), lds, s, P);
+        if (P.bf16) LAUNCH_K(1, true, true) else LAUNCH_K(1, true, false)
     } else
     switch (r) {
         LAUNCH_R(1) LAUNCH_R(2) LAUNCH_R(4) LAUNCH_R(8) LAUNCH_R(16)
         default: return hipErrorInvalidValue;
     }
 #undef LAUNCH_R
+#undef LAUNCH_K
 #ifdef SSMI_STAMP
     {
         (void)hipStreamSynchronize(s);

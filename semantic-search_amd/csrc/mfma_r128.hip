@@ -27,7 +27,7 @@ static constexpr int RQ_SLOT = 16 * 1024;  // one query slab: 2 k-halves x (128 
 
 // NT: 16-query blocks actually scored (1, 4 or 8): a batch of <= 16 queries costs 4 MFMAs and 2 fragment reads
 // per step and wave instead of 32 and 16, and leaves the registers for a ring of 8 steps.
-template <int R, int PD, int NT>
+template <int R, int PD, int NT, bool BF = false>
 __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
     constexpr int QD = PD + 1;          // query ring slots
     extern __shared__ __align__(16) unsigned char smem[];
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
                         for (int n = 0; n < NT; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(areg[u][m][kh], b[n], acc[m][n], 0, 0, 0);
+                            acc[m][n] = mfma16<BF>(areg[u][m][kh], b[n], acc[m][n]);
                 }
                 {   // refill the ring slot with step g + PD (the next row tile's rows when this one is used up;
                     // past the end of the slice: this step again, never consumed)
@@ -282,19 +282,20 @@ template <int PD, int NT>
 static hipError_t launch_pd(const MfmaParams& P, int r, int grid, hipStream_t s) {
     const size_t lds = (size_t)(PD + 1) * RQ_SLOT + 4 * N128_TN * 4 + 16;
     hipError_t e;
-#define LAUNCH_R(RR)                                                                                    \
-    case RR: {                                                                                          \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(flat_mfma_r128_kernel<RR, PD, NT>),      \
+#define LAUNCH_K(...)                                                                                   \
+    {                                                                                                   \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(flat_mfma_r128_kernel<__VA_ARGS__>),     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
         if (e != hipSuccess) return e;                                                                  \
-        hipLaunchKernelGGL((flat_mfma_r128_kernel<RR, PD, NT>), dim3(grid), dim3(512), lds, s, P);     \
-        break;                                                                                          \
+        hipLaunchKernelGGL((flat_mfma_r128_kernel<__VA_ARGS__>), dim3(grid), dim3(512), lds, s, P);    \
     }
+#define LAUNCH_R(RR) case RR: if (P.bf16) LAUNCH_K(RR, PD, NT, true) else LAUNCH_K(RR, PD, NT, false) break;
     switch (r) {
         LAUNCH_R(1) LAUNCH_R(2) LAUNCH_R(4)
         default: return hipErrorInvalidValue;
     }
 #undef LAUNCH_R
+#undef LAUNCH_K
     return hipGetLastError();
 }
 

@@ -1,5 +1,5 @@
 // scan_impl.h - K1: bandwidth-bound streaming scan with fused per-wavefront
-// top-k (small query batches).  Included by scan_f32.hip / scan_f16.hip.
+// top-k (small query batches).  Included by scan_f32.hip / scan_f16.hip / scan_bf16.hip.
 //
 // Replaces the hot loop behind faiss.IndexFlatIP.search as called from
 // core/index_manager.py:371 of the reference (batch-1 in the reference).
@@ -28,6 +28,7 @@ namespace ssmi {
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<float> { static const int V = 4; };
 template <> struct ElemTraits<__half> { static const int V = 8; };
+template <> struct ElemTraits<bf16_t> { static const int V = 8; };
 
 __device__ __forceinline__ uint4 load16(const void* p) {
     return *reinterpret_cast<const uint4*>(p);
@@ -61,6 +62,17 @@ template <> struct Unpack<__half> {
             const __half2 h = *reinterpret_cast<const __half2*>(&w[i]);
             const float2 p = __half22float2(h);
             f[2 * i] = p.x; f[2 * i + 1] = p.y;
+        }
+    }
+};
+
+template <> struct Unpack<bf16_t> {   // bf16 -> fp32 is a shift / a mask: element 2i sits in the low half of word i
+    __device__ __forceinline__ static void run(const uint4& x, float* f) {
+        const unsigned w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
         }
     }
 };

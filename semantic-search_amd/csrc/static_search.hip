@@ -105,8 +105,7 @@ int ssmi_index_search_static(ssmi_index* h, int64_t nq, const float* q_dev, int 
     // but this entry point does not rely on the previous user of the array having finished cleanly)
     HIPCHECK(hipMemsetAsync(counters, 0, (size_t)p.grid_y * sizeof(unsigned), s));
     p.tail = TailMerge{counters, D_dev, I_dev, id_offset, nullptr, nullptr, nullptr, nullptr, 0};
-    if (R.dtype == SSMI_F32) HIPCHECK(launch_flat_scan_f32(R.view(), q_dev, (int)nq, k, partial, p, s));
-    else HIPCHECK(launch_flat_scan_f16(R.view(), q_dev, (int)nq, k, partial, p, s));
+    HIPCHECK(launch_flat_scan(R.dtype, R.view(), q_dev, (int)nq, k, partial, p, s));
     return 0;
     });
 }

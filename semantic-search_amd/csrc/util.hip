@@ -1,5 +1,5 @@
 // util.hip - small data-movement kernels around the row store:
-//   K4  cvt_store         add():  (n,d) fp32/fp16 rows -> padded storage rows
+//   K4  cvt_store         add():  (n,d) fp32/fp16/bf16 rows -> padded storage rows
 //   K9  gather_rows       reconstruct_n(): storage rows by id -> (n,d) fp32
 //   K10 fill_random_unit  bench/test data: N(0,1) components, unit L2 norm
 // Reference call sites these stand behind: index.add (core/index_manager.py:319),
@@ -31,14 +31,14 @@ hipError_t launch_cvt_store(const void* src, int src_dtype, long long n, int d, 
                             void* const* segs_rw, long long row0, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const dim3 grid((unsigned)n), block(256);
-    if (src_dtype == 0 && dst_dtype == 0)
-        hipLaunchKernelGGL((cvt_store_kernel<float, float>), grid, block, 0, s, (const float*)src, n, d, X.ld, segs_rw, X.seg_shift, row0);
-    else if (src_dtype == 0 && dst_dtype == 1)
-        hipLaunchKernelGGL((cvt_store_kernel<float, __half>), grid, block, 0, s, (const float*)src, n, d, X.ld, segs_rw, X.seg_shift, row0);
-    else if (src_dtype == 1 && dst_dtype == 0)
-        hipLaunchKernelGGL((cvt_store_kernel<__half, float>), grid, block, 0, s, (const __half*)src, n, d, X.ld, segs_rw, X.seg_shift, row0);
-    else
-        hipLaunchKernelGGL((cvt_store_kernel<__half, __half>), grid, block, 0, s, (const __half*)src, n, d, X.ld, segs_rw, X.seg_shift, row0);
+    if (!dtype_known(src_dtype) || !dtype_known(dst_dtype)) return hipErrorInvalidValue;
+#define CVT(S, T) hipLaunchKernelGGL((cvt_store_kernel<S, T>), grid, block, 0, s, (const S*)src, n, d, X.ld, segs_rw, X.seg_shift, row0)
+#define CVT_TO(S) { if (dst_dtype == 0) CVT(S, float); else if (dst_dtype == 1) CVT(S, __half); else CVT(S, bf16_t); }
+    if (src_dtype == 0) CVT_TO(float)
+    else if (src_dtype == 1) CVT_TO(__half)
+    else CVT_TO(bf16_t)
+#undef CVT_TO
+#undef CVT
     return hipGetLastError();
 }
 
@@ -65,7 +65,8 @@ hipError_t launch_gather_rows(const RowView& X, int dtype, const int64_t* ids, l
     if (n <= 0) return hipSuccess;
     const dim3 grid((unsigned)n), block(256);
     if (dtype == 0) hipLaunchKernelGGL((gather_rows_kernel<float>), grid, block, 0, s, X, ids, n, d, out, bad);
-    else hipLaunchKernelGGL((gather_rows_kernel<__half>), grid, block, 0, s, X, ids, n, d, out, bad);
+    else if (dtype == 1) hipLaunchKernelGGL((gather_rows_kernel<__half>), grid, block, 0, s, X, ids, n, d, out, bad);
+    else hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), grid, block, 0, s, X, ids, n, d, out, bad);
     return hipGetLastError();
 }
 
@@ -106,7 +107,8 @@ hipError_t launch_score_rows(const RowView& X, int dtype, const int64_t* ids, lo
     if (n <= 0 || n_neg <= 0) return hipSuccess;
     const dim3 grid((unsigned)n), block(256);
     if (dtype == 0) hipLaunchKernelGGL((score_rows_kernel<float>), grid, block, 0, s, X, ids, n, d, neg, n_neg, out, bad);
-    else hipLaunchKernelGGL((score_rows_kernel<__half>), grid, block, 0, s, X, ids, n, d, neg, n_neg, out, bad);
+    else if (dtype == 1) hipLaunchKernelGGL((score_rows_kernel<__half>), grid, block, 0, s, X, ids, n, d, neg, n_neg, out, bad);
+    else hipLaunchKernelGGL((score_rows_kernel<bf16_t>), grid, block, 0, s, X, ids, n, d, neg, n_neg, out, bad);
     return hipGetLastError();
 }
 
@@ -176,31 +178,47 @@ hipError_t launch_fill_random_unit(const RowView& X, int dtype, void* const* seg
     const int wpb = 4;
     const dim3 grid((unsigned)((n + wpb - 1) / wpb)), block(64 * wpb);
     if (dtype == 0) hipLaunchKernelGGL((fill_random_unit_kernel<float>), grid, block, 0, s, segs_rw, X.seg_shift, X.ld, row0, n, d, seed);
-    else hipLaunchKernelGGL((fill_random_unit_kernel<__half>), grid, block, 0, s, segs_rw, X.seg_shift, X.ld, row0, n, d, seed);
+    else if (dtype == 1) hipLaunchKernelGGL((fill_random_unit_kernel<__half>), grid, block, 0, s, segs_rw, X.seg_shift, X.ld, row0, n, d, seed);
+    else hipLaunchKernelGGL((fill_random_unit_kernel<bf16_t>), grid, block, 0, s, segs_rw, X.seg_shift, X.ld, row0, n, d, seed);
     return hipGetLastError();
 }
 
-// fp32 store rows [row0,row0+n) -> fp16 store rows (same row numbers): the fp16 shadow that lets
-// large query batches over an fp32 index run on the MFMA kernel
-__global__ void shadow_rows_kernel(RowView src, void* const* dsegs, int dshift, long long row0, long long n) {
+// fp32 store rows [row0,row0+n) -> 16-bit store rows (same row numbers): the shadow that lets large query batches
+// over an fp32 index run on the MFMA kernel.  BF: bf16 shadow (else fp16); *inexact (optional) is set when a value
+// does not survive the narrowing bit for bit (bf16: any of the low 16 bits set; fp16: the round trip differs).
+template <bool BF>
+__global__ void shadow_rows_kernel(RowView src, void* const* dsegs, int dshift, long long row0, long long n, int* inexact) {
     const long long i = blockIdx.x;
     if (i >= n) return;
     const long long r = row0 + i;
     const float* s = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(src.segs[r >> src.seg_shift]) +
                                                     (size_t)(r & ((1ll << src.seg_shift) - 1)) * (size_t)src.ld * 4);
-    __half* d = reinterpret_cast<__half*>(row_ptr_rw(dsegs, dshift, r, (size_t)src.ld * 2));
+    unsigned char* d = row_ptr_rw(dsegs, dshift, r, (size_t)src.ld * 2);
+    bool lossy = false;
     for (int e = threadIdx.x * 4; e < src.ld; e += blockDim.x * 4) {
         const float4 v = *reinterpret_cast<const float4*>(s + e);
-        __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
         uint2 o;
-        o.x = *reinterpret_cast<unsigned*>(&a);
-        o.y = *reinterpret_cast<unsigned*>(&b);
-        *reinterpret_cast<uint2*>(d + e) = o;
+        if (BF) {
+            const bf16_t a(v.x), b(v.y), c(v.z), dd(v.w);
+            o.x = (unsigned)a.x | ((unsigned)b.x << 16);
+            o.y = (unsigned)c.x | ((unsigned)dd.x << 16);
+            lossy |= (float)a != v.x || (float)b != v.y || (float)c != v.z || (float)dd != v.w;
+        } else {
+            __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+            o.x = *reinterpret_cast<unsigned*>(&a);
+            o.y = *reinterpret_cast<unsigned*>(&b);
+            const float2 ra = __half22float2(a), rb = __half22float2(b);
+            lossy |= ra.x != v.x || ra.y != v.y || rb.x != v.z || rb.y != v.w;
+        }
+        *reinterpret_cast<uint2*>(d + (size_t)e * 2) = o;
     }
+    if (inexact && __builtin_amdgcn_ballot_w64(lossy) != 0 && lane_id() == 0) atomicExch(inexact, 1);
 }
-hipError_t launch_shadow_rows(const RowView& src, void* const* dsegs, int dshift, long long row0, long long n, hipStream_t s) {
+hipError_t launch_shadow_rows(const RowView& src, void* const* dsegs, int dshift, int dst_dtype, long long row0, long long n,
+                              int* inexact, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(shadow_rows_kernel, dim3((unsigned)n), dim3(256), 0, s, src, dsegs, dshift, row0, n);
+    if (dst_dtype == 2) hipLaunchKernelGGL(shadow_rows_kernel<true>, dim3((unsigned)n), dim3(256), 0, s, src, dsegs, dshift, row0, n, inexact);
+    else hipLaunchKernelGGL(shadow_rows_kernel<false>, dim3((unsigned)n), dim3(256), 0, s, src, dsegs, dshift, row0, n, inexact);
     return hipGetLastError();
 }
 

@@ -17,7 +17,8 @@ sniffs the substrings "IVFPQ" / "IVFFlat" / "HNSW" in type(index).__name__.
 Flat objects deliberately have no `nlist` / `nprobe` / `hnsw` attributes, because
 get_index_stats / set_search_params branch on hasattr (core/index_factory.py:230-236,317-320).
 
-Additive (not in the reference): `storage="f16"` row storage, torch tensors on a
+Additive (not in the reference): `storage="f16"` / `storage="bf16"` row storage (bf16 is LOSSLESS for the
+reference's embeddings, which are bf16 model outputs cast to fp32: core/model_wrapper.py:201-203), torch tensors on a
 ROCm device accepted by add/search (device pointers are handed straight to the
 kernels), `search(..., id_offset=)` for row-sharded databases, `reconstruct_batch`.
 
@@ -38,7 +39,17 @@ METRIC_INNER_PRODUCT = 0
 METRIC_L2 = 1
 
 _STORAGE = {"f32": _lib.F32, "fp32": _lib.F32, "float32": _lib.F32, "f16": _lib.F16, "fp16": _lib.F16,
-            "float16": _lib.F16}
+            "float16": _lib.F16, "bf16": _lib.BF16, "bfloat16": _lib.BF16}
+_STORAGE_NAME = {_lib.F32: "f32", _lib.F16: "f16", _lib.BF16: "bf16"}
+# torch dtypes the engine takes as they are (anything else is widened to float32 first)
+_TORCH_SRC = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+
+
+def _device_rows(x: torch.Tensor):
+    """(contiguous tensor, source dtype code) of a device tensor of vectors."""
+    if x.dtype not in _TORCH_SRC:
+        x = x.float()
+    return x.contiguous(), _TORCH_SRC[x.dtype]
 
 
 def _floor32(min_score) -> float:
@@ -129,7 +140,7 @@ class _IndexBase:
 
     @property
     def storage(self) -> str:
-        return "f16" if self._get_int(self._lib.ssmi_index_get_storage_dtype) == _lib.F16 else "f32"
+        return _STORAGE_NAME[self._get_int(self._lib.ssmi_index_get_storage_dtype)]
 
     # -- add / train ------------------------------------------------------
     def train(self, x) -> None:
@@ -155,11 +166,8 @@ class _IndexBase:
         """Append vectors; ids are the running row numbers (FAISS add() without ids)."""
         if isinstance(x, torch.Tensor) and x.is_cuda:
             self._check_tensor(x, "add")
-            if x.dtype not in (torch.float32, torch.float16):
-                x = x.float()
-            x = x.contiguous()
+            x, dt = _device_rows(x)
             torch.cuda.current_stream(x.device).synchronize()  # the library copies on its own stream
-            dt = _lib.F32 if x.dtype == torch.float32 else _lib.F16
             _lib.check(self._lib.ssmi_index_add(self._handle(), x.shape[0], x.data_ptr(), dt, _lib.DEVICE))
             return
         if isinstance(x, torch.Tensor):
@@ -295,6 +303,13 @@ class _IndexBase:
         return self._shadow_state()[1]
 
     @property
+    def shadow_dtype(self) -> Optional[str]:
+        """Element type of the shadow: "f16", "bf16" (chosen while every fp32 row is bf16-valued: the shadow is then an
+        exact copy), or None while there is none."""
+        dt = self._get_int(self._lib.ssmi_index_get_shadow_dtype)
+        return None if dt < 0 else _STORAGE_NAME[dt]
+
+    @property
     def fp16_shadow_failed(self) -> bool:
         """The last attempt to build the shadow ran out of HBM; searches fell back to the exact scan."""
         return self._shadow_state()[2]
@@ -374,11 +389,8 @@ class IndexIVFFlat(_IndexBase):
         ids id0 + i (every rank of a sharded index passes the same x)."""
         if isinstance(x, torch.Tensor) and x.is_cuda:
             self._check_tensor(x, "add_shard")
-            if x.dtype not in (torch.float32, torch.float16):
-                x = x.float()
-            x = x.contiguous()
+            x, dt = _device_rows(x)
             torch.cuda.current_stream(x.device).synchronize()
-            dt = _lib.F32 if x.dtype == torch.float32 else _lib.F16
             _lib.check(self._lib.ssmi_index_add_ivf_shard(self._handle(), x.shape[0], x.data_ptr(), dt, _lib.DEVICE,
                                                           int(id0), int(shard), int(nshards)))
             return
@@ -392,11 +404,9 @@ class IndexIVFFlat(_IndexBase):
         """(keepalive, pointer, n, src dtype, mem kind) of a numpy array / CPU tensor / device tensor of vectors."""
         if isinstance(x, torch.Tensor) and x.is_cuda:
             self._check_tensor(x, what)
-            if x.dtype not in (torch.float32, torch.float16):
-                x = x.float()
-            x = x.contiguous()
+            x, dt = _device_rows(x)
             torch.cuda.current_stream(x.device).synchronize()  # the library works on its own stream
-            return x, x.data_ptr(), x.shape[0], (_lib.F32 if x.dtype == torch.float32 else _lib.F16), _lib.DEVICE
+            return x, x.data_ptr(), x.shape[0], dt, _lib.DEVICE
         if isinstance(x, torch.Tensor):
             x = x.numpy()
         x = _as_f32_matrix(x, self.d, what)

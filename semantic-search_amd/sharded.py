@@ -327,10 +327,13 @@ class ShardedIVFFlat(_ShardedSearch):
         own = torch.arange(id0, id0 + n, dtype=torch.int64) if ids is None else ids
         meta = torch.stack([labels, own], dim=1)[order].contiguous().to(dev)
         xs = x.to(dev)
-        if xs.dtype not in (torch.float32, torch.float16):
+        if xs.dtype not in (torch.float32, torch.float16, torch.bfloat16):
             xs = xs.float()
-        if getattr(self.local, "storage", "f32") == "f16":
+        storage = getattr(self.local, "storage", "f32")
+        if storage == "f16":
             xs = xs.half()  # what the owner stores anyway (same round-to-nearest-even): halves the bytes on the links
+        elif storage == "bf16":
+            xs = xs.bfloat16()
         xs = xs[order.to(xs.device)].contiguous()
         nrecv = int(sum(recv_counts))
         meta_r = torch.empty((nrecv, 2), dtype=torch.int64, device=dev)

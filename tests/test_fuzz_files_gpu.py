@@ -135,9 +135,9 @@ def test_append_after_a_torn_or_stale_journal_keeps_every_vector(ssa, tmp_path):
     jp = str(pi) + ".journal"
     raw = open(jp, "rb").read()
     extra = unit_rows(50, d, 77)
-    rec1_end = 28 + 12 + 200 * (4 + 8 + d * 4)
+    rec1_end = 32 + 12 + 200 * (4 + 8 + d * 4)        # header: fourcc, d:i32, nlist:u64, base ntotal:i64, base bytes:u64
     assert len(raw) == rec1_end + 12 + 100 * (4 + 8 + d * 4)
-    for cut in (rec1_end + 5, rec1_end + 12 + 37, len(raw) - 1, 28 + 3, 11):
+    for cut in (rec1_end + 5, rec1_end + 12 + 37, len(raw) - 1, 32 + 3, 11):
         open(jp, "wb").write(raw[:cut])
         ix = ssa.read_index(pi)
         kept = ix.ntotal

@@ -115,9 +115,11 @@ def test_train_kmeans_quality_and_recall(ssa, monkeypatch, spherical):
         np.testing.assert_allclose(norms, 1.0, atol=2e-6)
     else:
         assert norms.max() < 0.999   # means of unit rows that do not coincide lie inside the sphere
-    _, obj_ref = ivf_flat.kmeans(X, nlist, spherical=spherical)
+    # Lloyd iterations end in a local optimum that depends on the initial centroids (the oracle's objective spreads 6-8 %
+    # over its seeds on these rows): the index must land inside the oracle's range, not above one run of it
+    objs = [ivf_flat.kmeans(X, nlist, seed=sd, spherical=spherical)[1] for sd in (1234, 1, 2, 3)]
     obj = ivf_flat.objective(X, C)
-    assert obj > 0.97 * obj_ref, (obj, obj_ref)
+    assert 0.985 * min(objs) <= obj <= 1.02 * max(objs), (obj, objs)
     index.add(X)
     assert int(index.list_sizes().sum()) == n
     assert ivf_flat.assignment_is_valid(X, C, index.assignments(), rtol=2e-3)
@@ -141,8 +143,8 @@ def test_spherical_kmeans_on_rows_of_unequal_norm(ssa):
     index.train(X)
     C = index.get_centroids()
     np.testing.assert_allclose(np.linalg.norm(C.astype(np.float64), axis=1), 1.0, atol=2e-6)
-    _, obj_ref = ivf_flat.kmeans(X, nlist, spherical=True)
-    assert ivf_flat.objective(X, C) > 0.97 * obj_ref
+    objs = [ivf_flat.kmeans(X, nlist, seed=sd, spherical=True)[1] for sd in (1234, 1, 2, 3)]
+    assert 0.985 * min(objs) <= ivf_flat.objective(X, C) <= 1.02 * max(objs), objs
     index.add(X)
     sizes = index.list_sizes()
     assert sizes.max() < 6 * n / nlist, sizes   # no list swallows the index
