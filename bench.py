@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--d", type=int, default=4096)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--storage", default="f32", choices=["f32", "f16"])
+    ap.add_argument("--storage", default="f32", choices=["f32", "f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="only the bench line itself: no side measurements")
     ap.add_argument("--no-ivf-extra", action="store_true", help="skip the IVF4096 / 10M-row side measurement (configs[3])")
@@ -525,6 +525,31 @@ def run_ivf(args, D, emit=True, with_cpu=True):
             line["cpu_baseline"] = cpu_baseline_ivf(ivf, flat, d, k, nprobe, n)
         except Exception as e:
             line["cpu_baseline"] = {"error": repr(e)}
+    if with_cpu and not sharded:
+        # k-means of the coarse quantizer, both modes on the same rows: spherical (default; what FAISS's IndexIVF does for
+        # the inner product [FAISS-lib]) against plain means (SSMI_IVF_SPHERICAL=0, rounds 1-2): list sizes and recall@k
+        modes = {"spherical": {"list_sizes": line["extra"]["list_sizes_rank0"], "recall_at_%d_vs_flat" % k: recall,
+                               "batch_1_qps": line["value"]}}
+        ivf.close()
+        os.environ["SSMI_IVF_SPHERICAL"] = "0"
+        try:
+            ivf = ssa.IndexIVFFlat(ssa.IndexFlatIP(d, storage="f16"), d, nlist, ssa.METRIC_INNER_PRODUCT, storage="f16")
+        finally:
+            del os.environ["SSMI_IVF_SPHERICAL"]
+        ivf.train(ivf_rows_factory(args, dev, n, seed=99)(ntrain))
+        rows = ivf_rows_factory(args, dev, n, seed=1234 + rank)
+        for s0 in range(0, n_local, 65536):
+            ivf.add(rows(min(65536, n_local - s0), row0 + s0))
+        ivf.nprobe = nprobe
+        ivf.set_timing(False)
+        el = D.timed(lambda i: ivf.search(Q[i % 1000:i % 1000 + 1], k), args.steps, args.warmup)
+        _, Ip = ivf.search(Q, k)
+        torch.cuda.synchronize()
+        ls2 = ivf.list_sizes()
+        modes["plain_means"] = {"list_sizes": {"min": int(ls2.min()), "median": float(np.median(ls2)), "max": int(ls2.max())},
+                                "recall_at_%d_vs_flat" % k: recall_at(Ip.cpu().numpy(), If.cpu().numpy(), k),
+                                "batch_1_qps": args.steps / el}
+        line["extra"]["kmeans_modes"] = modes
     ivf.close(); flat.close()
     if emit and rank == 0:
         print(json.dumps(line), flush=True)
@@ -543,7 +568,8 @@ def side_batches(index, local, n_local, args, D, g):
         e = {"workload": flat_workload_label(args.n, args.d, args.storage, B, args.k, D.world),
              "qps": B * steps / el, "ms_per_step": el / steps * 1e3, "kernel_avg_ms": roof["kernel_avg_ms"],
              "kernel": roof["kernel"], "achieved_tflops_per_gpu": roof["algorithmic_flops_per_launch"] / (roof["kernel_avg_ms"] * 1e-3) / 1e12,
-             "operand_dtype": "f16 (shadow copy of the f32 rows), f32 accumulate" if args.storage == "f32" else "f16, f32 accumulate"}
+             "operand_dtype": ("%s (shadow copy of the f32 rows), f32 accumulate" % (local.shadow_dtype or "f16")) if args.storage == "f32"
+                              else "%s, f32 accumulate" % args.storage}
         e["mfma_frac_of_2.5PF"] = e["achieved_tflops_per_gpu"] / MFMA_F16_PEAK_TFLOPS
         if D.world == 1:
             # recall of the batched path against the exact streaming scan (fp32 queries, stored rows as they are)
@@ -556,8 +582,9 @@ def side_batches(index, local, n_local, args, D, g):
                 del os.environ["SSMI_NO_SHADOW"]; del os.environ["SSMI_MFMA_MIN_B"]
             torch.cuda.synchronize()
             e["recall_at_%d_vs_exact_scan" % args.k] = recall_at(Ib[sel].cpu().numpy(), Ie.cpu().numpy(), args.k)
-            e["recall_note"] = ("64 of the queries; exact scan = K1 with fp32 queries over the %s rows; the batched path rounds queries%s to fp16"
-                                % (args.storage, " and rows (shadow)" if args.storage == "f32" else ""))
+            e["recall_note"] = ("64 of the queries; exact scan = K1 with fp32 queries over the %s rows; the batched path rounds queries%s to %s"
+                                % (args.storage, " and rows (shadow)" if args.storage == "f32" else "",
+                                   (local.shadow_dtype or "f16") if args.storage == "f32" else args.storage))
         out["batch_%d" % B] = e
     try:  # counter-based MFMA utilisation of the batch-4096 contraction (committed PMC pass, labelled as such)
         for tag in ("r02", "r01"):
@@ -573,46 +600,63 @@ def side_batches(index, local, n_local, args, D, g):
     return out
 
 
-def add_same_unit_rows(indexes, n, d, dev, seed):
+def add_same_unit_rows(indexes, n, d, dev, seed, bf16_valued=False):
     """The same device-generated unit rows (N(0,1) components, L2-normalised) appended to every index of the
-    list, through the product's own add() (fp16 storage rounds to nearest even there)."""
+    list, through the product's own add() (16-bit storage rounds to nearest even there).  bf16_valued: the rows are
+    rounded to bf16 and widened again first - what the reference's embedder hands over (bf16 model outputs cast to
+    fp32, core/model_wrapper.py:201-203)."""
     gd = torch.Generator(device=dev).manual_seed(seed)
     for s0 in range(0, n, 65536):
         x = torch.randn((min(65536, n - s0), d), generator=gd, device=dev)
         x /= x.norm(dim=1, keepdim=True)
+        if bf16_valued:
+            x = x.bfloat16().float()
         for ix in indexes:
             ix.add(x)
 
 
-def side_fp16_recall(args, D, g):
-    """north_star: 'the fp16-storage recall@10 loss stated separately'.  The same 1M device-generated rows in an
-    f32 and an f16 index (same seed, same pre-rounding values), 256 queries: recall@10 of fp16 storage against
-    the fp32 result, on the exact scan (fp32 queries) and on the MFMA path (fp16 queries)."""
+def side_storage_recall(args, D, g):
+    """north_star: 'the fp16-storage recall@10 loss stated separately' - and the same for bf16 storage, side by side.
+    The same 1M device-generated rows in an f32, an f16 and a bf16 index, 256 queries: recall@10 of each 16-bit
+    storage against the fp32 result, on the exact scan (fp32 queries) and on the MFMA path (queries narrowed to the
+    rows' type).  Twice: on generic fp32 rows, and on bf16-VALUED rows and queries (the reference's producer)."""
     import semantic_search_amd as ssa
     n, d, k, nq = 1_000_000, args.d, 10, 256
-    a, b = ssa.IndexFlatIP(d, storage="f32"), ssa.IndexFlatIP(d, storage="f16")
-    add_same_unit_rows([a, b], n, d, D.dev, 1234)
-    same = np.array_equal(a.reconstruct_batch([0, 77777, n - 1]).astype(np.float16).astype(np.float32), b.reconstruct_batch([0, 77777, n - 1]))
-    Q = unit_queries(g, (nq, d), D.dev)
-    os.environ["SSMI_NO_SHADOW"] = "1"; os.environ["SSMI_MFMA_MIN_B"] = "1000000"
-    try:
-        D32, I32 = a.search(Q, k)
-        D16, I16 = b.search(Q, k)
-    finally:
-        del os.environ["SSMI_NO_SHADOW"]; del os.environ["SSMI_MFMA_MIN_B"]
-    D16m, I16m = b.search(Q, k)
-    mfma_kernel = b.last_kernel()
-    torch.cuda.synchronize()
-    I32, I16, I16m = I32.cpu().numpy(), I16.cpu().numpy(), I16m.cpu().numpy()
-    rel = float((torch.abs(D16 - D32) / torch.abs(D32)).max().item())
-    out = {"workload": "Flat IP %dx%d, the same rows stored as f32 and as f16 (fp16-rounded once at add), %d queries, k=%d" % (n, d, nq, k),
-           "f16_rows_are_the_rounded_f32_rows": bool(same),
-           "recall_at_10_f16_storage_exact_scan_vs_f32": recall_at(I16, I32, k),
-           "recall_at_10_f16_storage_mfma_vs_f32": recall_at(I16m, I32, k), "mfma_kernel": mfma_kernel,
-           "top1_agreement_f16_storage_vs_f32": float(np.mean(I16[:, 0] == I32[:, 0])),
-           "max_rel_score_diff_rank_by_rank": rel,
-           "note": "differences are swaps among candidates whose fp32 scores tie within the fp16 rounding of a row (~1e-5 absolute on unit vectors)"}
-    a.close(); b.close()
+    out = {"workload": "Flat IP %dx%d, the same rows stored as f32, f16 and bf16 (rounded once at add), %d queries, k=%d" % (n, d, nq, k)}
+    for label, valued in (("generic_fp32_rows", False), ("bf16_valued_rows_and_queries", True)):
+        a, b, c = ssa.IndexFlatIP(d, storage="f32"), ssa.IndexFlatIP(d, storage="f16"), ssa.IndexFlatIP(d, storage="bf16")
+        add_same_unit_rows([a, b, c], n, d, D.dev, 1234, bf16_valued=valued)
+        Q = unit_queries(g, (nq, d), D.dev)
+        if valued:
+            Q = Q.bfloat16().float()
+        os.environ["SSMI_NO_SHADOW"] = "1"; os.environ["SSMI_MFMA_MIN_B"] = "1000000"
+        try:
+            D32, I32 = a.search(Q, k)
+            D16, I16 = b.search(Q, k)
+            Db, Ib = c.search(Q, k)
+        finally:
+            del os.environ["SSMI_NO_SHADOW"]; del os.environ["SSMI_MFMA_MIN_B"]
+        D16m, I16m = b.search(Q, k)
+        kern = b.last_kernel()
+        Dbm, Ibm = c.search(Q, k)
+        Dsh, Ish = a.search(Q, k)   # fp32 rows through their 16-bit shadow (auto: bf16 while lossless, else fp16)
+        torch.cuda.synchronize()
+        ref = I32.cpu().numpy()
+        e = {"recall_at_10_f16_storage_exact_scan_vs_f32": recall_at(I16.cpu().numpy(), ref, k),
+             "recall_at_10_f16_storage_mfma_vs_f32": recall_at(I16m.cpu().numpy(), ref, k),
+             "recall_at_10_bf16_storage_exact_scan_vs_f32": recall_at(Ib.cpu().numpy(), ref, k),
+             "recall_at_10_bf16_storage_mfma_vs_f32": recall_at(Ibm.cpu().numpy(), ref, k),
+             "recall_at_10_f32_storage_via_shadow_vs_f32_exact": recall_at(Ish.cpu().numpy(), ref, k),
+             "shadow_dtype_chosen": a.shadow_dtype, "mfma_kernel": kern,
+             "ids_identical_bf16_storage_exact_scan": bool(torch.equal(Ib, I32)),
+             "ids_identical_bf16_storage_mfma": bool(torch.equal(Ibm, I32)),
+             "ids_identical_f32_via_shadow": bool(torch.equal(Ish, I32)),
+             "max_rel_score_diff_f16": float((torch.abs(D16 - D32) / torch.abs(D32)).max().item()),
+             "max_rel_score_diff_bf16": float((torch.abs(Db - D32) / torch.abs(D32)).max().item())}
+        out[label] = e
+        a.close(); b.close(); c.close()
+    out["decision"] = ("the shadow of fp32 rows is bf16 while every row is bf16-valued (lossless: ids identical to the exact scan) "
+                       "and fp16 otherwise (11 significant bits against 8: the smaller recall loss on generic rows)")
     return out
 
 
@@ -751,7 +795,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32" if args.storage == "f32" and roof["bound"] == "hbm" else "f16 operands, f32 accumulate",
+            "dtype": ("f32" if args.storage == "f32" and roof["bound"] == "hbm" else
+                      "%s operands, f32 accumulate" % ((index.local.shadow_dtype or "f16") if args.storage == "f32" else args.storage)),
             "data": "synthetic",
             "config": {
                 "workload": flat_workload_label(args.n, args.d, args.storage, args.batch, args.k, world),
@@ -778,7 +823,7 @@ def main():
     index.local.close()
 
     if not args.no_extra and world == 1 and not D.forced:
-        guarded("fp16_storage_recall", lambda: side_fp16_recall(args, D, g))
+        guarded("storage_recall", lambda: side_storage_recall(args, D, g))
         if not args.no_ivf_extra:
             # BASELINE configs[3], IVF4096 nprobe 32 over 10M x 4096 f16 rows, the same procedure as
             # `bench.py --workload ivf`; clustered rows (IVF's use case) and iid rows (SURVEY.md 8d's generator)

@@ -233,6 +233,12 @@ int ssmi_index_set_timing(ssmi_index* h, int enabled);
 int ssmi_index_get_list_sizes(const ssmi_index* h, int64_t* out_host);
 /* ... and the list each stored vector was assigned to (ntotal int32, indexed by id) */
 int ssmi_index_get_assignments(const ssmi_index* h, int32_t* out_host);
+/* The members of inverted list `list` in stored order: their ids (int64) and, when vecs_out_host is not NULL, their
+ * vectors ((n, d) fp32).  cap = entries the buffers hold; *n_out = the list's size (nothing is written when it
+ * exceeds cap).  What faiss.write_index walks per list (invlists->get_ids / get_codes [FAISS-lib]) behind
+ * core/index_manager.py:241: the single-process multi-GPU index (multi_device.py) writes ONE FAISS file from the
+ * lists its shards own. */
+int ssmi_index_get_list_members(ssmi_index* h, int list, int64_t cap, int64_t* ids_out_host, float* vecs_out_host, int64_t* n_out);
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,8 @@ _SIGNATURES = {
     "ssmi_index_set_timing": [_c_index_p, ctypes.c_int],
     "ssmi_index_get_list_sizes": [_c_index_p, ctypes.c_void_p],
     "ssmi_index_get_assignments": [_c_index_p, ctypes.c_void_p],
+    "ssmi_index_get_list_members": [_c_index_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.POINTER(ctypes.c_int64)],
 }
 EXPORTED_SYMBOLS = ["ssmi_last_error"] + sorted(_SIGNATURES)
 

@@ -388,6 +388,34 @@ static int read_flat_into(ssmi_index* h, RowStore& R, FILE* f, int expect_d, int
     return 0;
 }
 
+// members of one inverted list, in stored order (ids, optionally vectors as fp32 on the host)
+int ssmi_index_get_list_members(ssmi_index* h, int list, int64_t cap, int64_t* ids_out_host, float* vecs_out_host, int64_t* n_out) {
+    return guarded([&]() -> int {
+    if (!h || !n_out) return fail("NULL argument");
+    if (h->kind != SSMI_KIND_IVFFLAT) return fail("get_list_members: not an IVF index");
+    if (list < 0 || list >= h->nlist) return fail("get_list_members: list %d out of range [0, %d)", list, h->nlist);
+    DeviceGuard g(h->device);
+    quiesce(h);
+    IvfState* S = st(h);
+    const long long n = S->size[list];
+    *n_out = n;
+    if (n == 0 || n > cap) return 0;
+    if (!ids_out_host) return fail("NULL buffer");
+    std::vector<int64_t> slots((size_t)n);
+    for (long long pos = 0; pos < n; ++pos)
+        slots[pos] = (long long)S->pages[list][pos >> kPageShift] * kPageRows + (pos & (kPageRows - 1));
+    // the ids of the list's slots: every page is a run of kPageRows slot ids
+    std::vector<uint32_t> page_ids((size_t)(n + kPageRows - 1) / kPageRows * kPageRows);
+    for (long long pg = 0; pg * kPageRows < n; ++pg)
+        HIPCHECK(hipMemcpyAsync(page_ids.data() + pg * kPageRows, S->d_slot_ids + (size_t)S->pages[list][pg] * kPageRows,
+                                (size_t)std::min<long long>(kPageRows, n - pg * kPageRows) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    for (long long j = 0; j < n; ++j) ids_out_host[j] = (int64_t)page_ids[(size_t)j];
+    if (vecs_out_host) CHECK(read_rows(h, h->rows, h->ivf_slots_used, slots.data(), n, vecs_out_host));
+    return 0;
+    });
+}
+
 int ssmi_index_read(const char* path, int storage_dtype, int device, ssmi_index** out) {
     return guarded([&]() -> int {
     if (!path || !out) return fail("NULL argument");

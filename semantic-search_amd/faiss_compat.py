@@ -335,7 +335,17 @@ class _IndexBase:
 class IndexFlatIP(_IndexBase):
     """Exact maximum-inner-product index (stand-in for faiss.IndexFlatIP)."""
 
-    def __init__(self, d: int, storage: str = "f32", device: Optional[int] = None, fp16_shadow: bool = True, _handle=None):
+    def __new__(cls, d: int = 0, storage: str = "f32", device: Optional[int] = None, fp16_shadow: bool = True,
+                devices=None, _handle=None):
+        """devices=[...] (additive): ONE index over several GPUs inside this process - rows sharded, results merged on
+        the first device (multi_device.MultiDeviceFlatIP); a device may be named several times (logical shards)."""
+        if devices is not None and cls is IndexFlatIP:
+            from .multi_device import MultiDeviceFlatIP
+            return MultiDeviceFlatIP(d, devices, storage=storage, fp16_shadow=fp16_shadow)
+        return super().__new__(cls)
+
+    def __init__(self, d: int, storage: str = "f32", device: Optional[int] = None, fp16_shadow: bool = True,
+                 devices=None, _handle=None):
         super().__init__()
         if _handle is not None:
             self._h = _handle
@@ -352,8 +362,17 @@ class IndexIVFFlat(_IndexBase):
     """Inverted-file index with exact inner products inside the probed lists
     (stand-in for faiss.IndexIVFFlat with METRIC_INNER_PRODUCT)."""
 
+    def __new__(cls, quantizer=None, d: int = 0, nlist: int = 0, metric: int = METRIC_INNER_PRODUCT, storage: str = "f32",
+                device: Optional[int] = None, fp16_shadow: bool = True, devices=None, _handle=None):
+        """devices=[...] (additive): the inverted lists sharded over several GPUs inside this process, list l on shard
+        l % len(devices) (multi_device.MultiDeviceIVFFlat)."""
+        if devices is not None and cls is IndexIVFFlat:
+            from .multi_device import MultiDeviceIVFFlat
+            return MultiDeviceIVFFlat(quantizer, d, nlist, metric, devices, storage=storage, fp16_shadow=fp16_shadow)
+        return super().__new__(cls)
+
     def __init__(self, quantizer, d: int, nlist: int, metric: int = METRIC_INNER_PRODUCT, storage: str = "f32",
-                 device: Optional[int] = None, fp16_shadow: bool = True, _handle=None):
+                 device: Optional[int] = None, fp16_shadow: bool = True, devices=None, _handle=None):
         super().__init__()
         self.quantizer = quantizer
         if _handle is not None:
@@ -450,6 +469,17 @@ class IndexIVFFlat(_IndexBase):
         return out
 
 
+    def list_members(self, l: int, with_vectors: bool = True):
+        """(ids int64 (n,), vectors float32 (n,d) or None) of inverted list l, in stored order."""
+        n = ctypes.c_int64()
+        _lib.check(self._lib.ssmi_index_get_list_members(self._handle(), int(l), 0, None, None, ctypes.byref(n)))
+        ids = np.empty((n.value,), dtype=np.int64)
+        vecs = np.empty((n.value, self.d), dtype=np.float32) if with_vectors else None
+        if n.value:
+            _lib.check(self._lib.ssmi_index_get_list_members(self._handle(), int(l), n.value, ids.ctypes.data,
+                                                             vecs.ctypes.data if with_vectors else None, ctypes.byref(n)))
+        return ids, vecs
+
     def assignments(self) -> np.ndarray:
         """List id of every stored vector, indexed by vector id (test introspection)."""
         out = np.empty((self.ntotal,), dtype=np.int32)
@@ -462,12 +492,19 @@ def write_index(index: _IndexBase, path, incremental: bool = False) -> None:
     earlier state of this index, only the vectors added since are written: a Flat index appends them to the file
     (same bytes as a full write); an IVF index appends a record to `<path>.journal`, which read_index replays on
     top of the base file (a full write, incremental=False, folds the journal back in and removes it)."""
+    if hasattr(index, "shards"):   # one index over several GPUs: ONE FAISS file, written from what the shards hold
+        index.write(path)
+        return
     fn = index._lib.ssmi_index_write_append if incremental else index._lib.ssmi_index_write
     _lib.check(fn(index._handle(), os.fsencode(str(path))))
 
 
-def read_index(path, storage: Optional[str] = None, device: Optional[int] = None) -> _IndexBase:
-    """Stand-in for faiss.read_index (core/index_manager.py:185)."""
+def read_index(path, storage: Optional[str] = None, device: Optional[int] = None, devices=None):
+    """Stand-in for faiss.read_index (core/index_manager.py:185).  devices=[...]: the file's vectors are spread over
+    several GPUs as they are read (multi_device.read_multi)."""
+    if devices is not None:
+        from .multi_device import read_multi
+        return read_multi(path, devices, storage=storage or "f32")
     lib = _lib.load()
     dev = _default_device() if device is None else int(device)
     h = ctypes.c_void_p()

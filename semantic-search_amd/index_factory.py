@@ -47,7 +47,7 @@ class IndexConfig:
     pq_bits: int = 8
     is_trained: bool = False
     training_size: int = 0
-    # additive, not serialised: engine options {"storage": "f32"|"f16", "device": int}
+    # additive, not serialised: engine options {"storage": "f32"|"f16"|"bf16", "device": int, "devices": [int, ...]}
     extra: Dict[str, Any] = field(default_factory=dict, repr=False, compare=False)
 
     _KEYS = ("nlist", "nprobe", "hnsw_m", "hnsw_ef_construction", "hnsw_ef_search", "pq_m", "pq_bits",
@@ -104,11 +104,12 @@ class IndexFactory:
     @staticmethod
     def create_index(config: IndexConfig):
         """core/index_factory.py:125-163"""
-        opts = {k: v for k, v in config.extra.items() if k in ("storage", "device")}
+        opts = {k: v for k, v in config.extra.items() if k in ("storage", "device", "devices")}
         if config.index_type == IndexType.FLAT:
             return faiss.IndexFlatIP(config.dimension, **opts)
         if config.index_type == IndexType.IVF_FLAT:
-            quantizer = faiss.IndexFlatIP(config.dimension, **opts)
+            # (one index over several GPUs keeps its coarse quantizer inside every shard: no separate object)
+            quantizer = None if "devices" in opts else faiss.IndexFlatIP(config.dimension, **opts)
             index = faiss.IndexIVFFlat(quantizer, config.dimension, config.nlist, faiss.METRIC_INNER_PRODUCT, **opts)
             index.nprobe = config.nprobe
             return index

@@ -161,13 +161,18 @@ class SemanticIndex:
 
     def __init__(self, index_name: str, embedding_dim: int = 4096, index_type: str = "flat",
                  base_path: Optional[Path] = None, storage: str = "f32", device: Optional[int] = None,
-                 check_files_exist: bool = True):
+                 check_files_exist: bool = True, devices: Optional[List[int]] = None):
         self.index_name = index_name
         self.embedding_dim = embedding_dim
         self.index_type_str = index_type
         self._engine_opts = {"storage": storage}
         if device is not None:
             self._engine_opts["device"] = device
+        if devices is not None:
+            # additive: ONE index over several GPUs inside this process (multi_device.py) - rows (Flat) or lists (IVF)
+            # sharded, results merged on the first device; what the reference's single process can hold
+            self._engine_opts.pop("device", None)
+            self._engine_opts["devices"] = [int(v) for v in devices]
         # the reference drops hits whose file has disappeared since indexing (:389); False skips the stat per hit
         self._check_files_exist = check_files_exist
         self.index_path = get_index_path(index_name, Path(base_path) if base_path else None)
