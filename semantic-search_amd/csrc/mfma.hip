@@ -39,9 +39,11 @@ namespace ssmi {
 // H: _Float16 or bf16_t (round to nearest even either way) - the operand type of the rows the batch will meet.
 template <typename H>
 __global__ void cvt_queries_16_kernel(const float* __restrict__ q, int nq, int ld, H* __restrict__ out,
-                                      unsigned* __restrict__ gthr, unsigned* __restrict__ gtop, int gtop_words, int pitch) {
+                                      unsigned* __restrict__ gthr, unsigned* __restrict__ gtop, int gtop_words, int pitch,
+                                      unsigned* __restrict__ xsync = nullptr) {
     const int i = blockIdx.x;  // padded row
     if (gthr && threadIdx.x == 0) gthr[i] = 0;
+    if (xsync && i == 0 && threadIdx.x < 8 * XSYNC_STRIDE) xsync[threadIdx.x] = 0;
     if (gtop)
         for (int e = threadIdx.x; e < gtop_words; e += blockDim.x) gtop[(size_t)i * gtop_words + e] = 0;
     const int off = (pitch - ld) / 2;
@@ -85,7 +87,7 @@ bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_c
     // fp16 queries (the 256-query kernel takes rows of ld + 64: see cvt_queries_f16_kernel) + shared thresholds + published tops
     p->q_pitch = p->narrow ? ld : ld + 64;
     p->qh_bytes = (size_t)p->nqt * TN * p->q_pitch * 2 + (size_t)p->nqt * TN * sizeof(unsigned) +
-                  (size_t)p->nqt * TN * p->nslices * p->gtop_m * sizeof(unsigned);
+                  (size_t)p->nqt * TN * p->nslices * p->gtop_m * sizeof(unsigned) + 8 * XSYNC_STRIDE * sizeof(unsigned);
     p->cand_bytes = (size_t)p->grid * TN * CAND_CAP * sizeof(skey_t);
     const char* env_r = getenv("SSMI_MFMA_R128");
     p->kernel = !p->narrow ? "flat_mfma_pp_kernel"
@@ -103,12 +105,13 @@ hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, con
     // (a batch of a few queries on the register-ring kernel gains nothing and pays for the ring drains of the exchange)
     const bool share_tops = share_thr && p.gtop_m > 0 && k > 1 && !(p.narrow && nq < 32 && k <= 16) && !(env_g && env_g[0] == '0');
     unsigned* gtop = gthr + (size_t)p.nqt * TN;
+    unsigned* xsync = gtop + (size_t)p.nqt * TN * p.nslices * p.gtop_m;
     if (p.dtype == 2)
         hipLaunchKernelGGL(cvt_queries_16_kernel<bf16_t>, dim3(p.nqt * TN), dim3(256), 0, s, Q, nq, X.ld, (bf16_t*)qh, gthr,
-                           share_tops ? gtop : (unsigned*)nullptr, p.nslices * p.gtop_m, p.q_pitch);
+                           share_tops ? gtop : (unsigned*)nullptr, p.nslices * p.gtop_m, p.q_pitch, xsync);
     else
         hipLaunchKernelGGL(cvt_queries_16_kernel<_Float16>, dim3(p.nqt * TN), dim3(256), 0, s, Q, nq, X.ld, (_Float16*)qh, gthr,
-                           share_tops ? gtop : (unsigned*)nullptr, p.nslices * p.gtop_m, p.q_pitch);
+                           share_tops ? gtop : (unsigned*)nullptr, p.nslices * p.gtop_m, p.q_pitch, xsync);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     MfmaParams P = {};
@@ -124,6 +127,23 @@ hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, con
     // than a slice's own k-th score) after 1, 16, 256, ... only (SSMI_MFMA_FOLD_MASK: bit b = a fold after tile 2^b)
     P.fold_mask = P.gtop ? 0x11111111u : 0x55555555u;
     if (const char* e = getenv("SSMI_MFMA_FOLD_MASK")) P.fold_mask = (unsigned)strtoul(e, nullptr, 16) | 1u;
+    // The workgroups of an XCD meet behind every row tile (mfma_pp.hip), so that the operand slabs they share are L2 hits and
+    // not fabric reads: the fabric-side traffic costs this power-limited kernel its clock.  Worth it on long slices only (a
+    // meeting costs the spread of the workgroups' tile times, the heavy folds come early): from 128 row tiles per slice on,
+    // from row tile 17 of a slice on.  With meetings an XCD takes a patch of 8 query tiles x 4 slices instead of all 16 query
+    // tiles of 2 slices (12 instead of 18 operand streams from beyond its L2).  SSMI_MFMA_SYNC=0/1 and SSMI_MFMA_PATCH=<query
+    // tiles per patch, 0 = none> override; SSMI_MFMA_SYNC_FROM / SSMI_MFMA_SYNC_POLLS tune the meeting.
+    const bool can_meet = !p.narrow && k > 1 && (p.grid % 8) == 0 && p.nslices > 1;
+    bool meet_on = can_meet && p.rows_per_slice / TM >= 128;
+    if (const char* e = getenv("SSMI_MFMA_SYNC")) meet_on = can_meet && e[0] == '1';
+    P.xsync = meet_on ? xsync : nullptr;
+    P.xsync_from = 17;
+    if (const char* e = getenv("SSMI_MFMA_SYNC_FROM")) P.xsync_from = atoi(e);
+    P.xsync_polls = 2048;   // about 2 ms: longer than any fold round
+    if (const char* e = getenv("SSMI_MFMA_SYNC_POLLS")) P.xsync_polls = atoi(e);
+    int patch = (meet_on && p.nqt >= 16 && p.nqt % 8 == 0) ? 8 : 0;
+    if (const char* e = getenv("SSMI_MFMA_PATCH")) patch = atoi(e);
+    P.patch_a = (patch > 0 && patch < p.nqt && p.nqt % patch == 0 && !p.narrow) ? patch : 0;
     int r = 1;
     while (64 * r < k) r <<= 1;
     if (p.narrow) {

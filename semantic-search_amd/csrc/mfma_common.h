@@ -20,6 +20,7 @@ __device__ __forceinline__ f32x4_t mfma16(const half8_t& a, const half8_t& b, co
 static constexpr int TM = 256, TN = 256, BK = 64;
 static constexpr int TILE_BYTES = TM * BK * 2;  // one operand tile: 32 KiB
 static constexpr int CAND_CAP = 512, CAND_TRIG = 256;
+static constexpr int XSYNC_STRIDE = 32;   // unsigned words between the arrival counters of two XCDs (one cache line each)
 
 struct MfmaParams {
     RowView X;                 // fp16 or bf16 rows (bf16 says which), ld % 64 == 0
@@ -40,6 +41,11 @@ struct MfmaParams {
     int gtop_m;
     int seed_first;            // 256-query kernel, k <= 16: the first row tile of a slice seeds its own threshold
     unsigned fold_mask;        // 256-query kernel: a scheduled fold follows row tile 2^b of the slice when bit b is set
+    int patch_a;               // 256-query kernel: query tiles per XCD patch (0: an XCD takes whole slices, all query tiles)
+    unsigned* xsync;           // 256-query kernel: [8][32] arrival counters, one per XCD (workgroups i % 8), zeroed by the query
+                               // conversion; nullptr: the workgroups of an XCD run free
+    int xsync_polls;           // ... bound of one wait, in polls of about a microsecond
+    int xsync_from;            // ... they meet from this row tile of their slices on (the first tiles carry the heavy folds)
 #ifdef SSMI_STAMP
     unsigned long long* dbg;   // diagnostic build only: per-wave cycle sums
 #endif

@@ -52,6 +52,27 @@
 #include <algorithm>
 #endif
 
+// timing-only builds (wrong results): SSMI_PP_HOT bit 0: every X piece reads the same cache-hot addresses, bit 1: every Q piece
+#ifndef SSMI_PP_HOT
+#define SSMI_PP_HOT 0
+#endif
+#if SSMI_PP_HOT & 4   // the pieces may land a phase later than they are read (how much of the time is waiting for them?)
+#define PP_T_WAIT4 "s_waitcnt vmcnt(8)"
+#elif SSMI_PP_HOT & 8  // ... two phases later
+#define PP_T_WAIT4 "s_waitcnt vmcnt(12)"
+#else
+#define PP_T_WAIT4 "s_waitcnt vmcnt(4)"
+#endif
+#if SSMI_PP_HOT & 1
+#define PP_T_OFFX(x) ((x) & 0u)
+#else
+#define PP_T_OFFX(x) (x)
+#endif
+#if SSMI_PP_HOT & 2
+#define PP_T_OFFQ(x) ((x) & 0u)
+#else
+#define PP_T_OFFQ(x) (x)
+#endif
 #ifndef SSMI_PP_PRIO
 #define SSMI_PP_PRIO 0  // 0: setprio(1) around every MFMA segment; 1: static priority for waves 4-7; 2: none
 #endif
@@ -84,7 +105,15 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
     const int nblocks = gridDim.x;
     int logical = blockIdx.x;
     if ((nblocks & 7) == 0) logical = (blockIdx.x & 7) * (nblocks >> 3) + (blockIdx.x >> 3);
-    const int slice = logical / P.nqt, qt = logical % P.nqt;
+    // An XCD's workgroups (consecutive logical numbers) form a patch of patch_a query tiles x slices: per row-tile step
+    // the XCD then pulls patch_a query tiles and (its workgroups / patch_a) row tiles through its L2 instead of all query
+    // tiles and two row tiles (the fabric-side traffic is what costs this kernel its clock)
+    int slice = logical / P.nqt, qt = logical % P.nqt;
+    if (P.patch_a > 0) {
+        const int per = P.nslices * P.patch_a, rem = logical % per;
+        slice = rem / P.patch_a;
+        qt = (logical / per) * P.patch_a + rem % P.patch_a;
+    }
     const int q0 = qt * TN;
     const long long r_begin = (long long)slice * P.rows_per_slice;
     const long long r_end = (r_begin + P.rows_per_slice < P.X.nrows) ? (r_begin + P.rows_per_slice) : P.X.nrows;
@@ -99,7 +128,7 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
         cnt_l[tid] = 0;
         kept_l[tid] = 0;
     }
-    if (tid == 0) *flag_l = 0;
+    if (tid == 0) { flag_l[0] = 0; flag_l[1] = 0; }   // [0]: a candidate buffer is half full, [1]: meetings in a row that the others did not come to (2: this workgroup has stopped meeting them)
     __syncthreads();
 
     const int ld = P.X.ld;
@@ -136,13 +165,13 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
 #define ISSUE_X(SL, KOFF, TOFF)                                                              \
     {                                                                                        \
         unsigned char* dst_ = smem + (SL) * SLAB + (wave * 4) * 1024;                        \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) GLDS16(asrc[j_] + (TOFF) + (KOFF), dst_ + j_ * 1024);          \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) GLDS16(asrc[j_] + PP_T_OFFX((TOFF) + (KOFF)), dst_ + j_ * 1024);          \
     }
 #define ISSUE_Q(SL, OFF)                                                                     \
     {                                                                                        \
         unsigned char* dst_ = smem + QRING + (SL) * SLAB + (wave * 4) * 1024;                \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                \
-            GLDS16(qbase + j_ * q_step + (piece_coff ^ ((j_ & 1) << 6)) + (OFF), dst_ + j_ * 1024);                       \
+            GLDS16(qbase + j_ * q_step + (piece_coff ^ ((j_ & 1) << 6)) + PP_T_OFFQ(OFF), dst_ + j_ * 1024);                       \
     }
     // pipeline fill of a row tile: X slab 0, the query piece in front of phase 0 (Q slot 0) and Q slab 0 (Q slot 1)
 #define ISSUE_FILL()                                                                         \
@@ -166,6 +195,19 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
 #define STAMP(i)
 #endif
     unsigned tiles_done = 0;
+    // The workgroups of an XCD (blockIdx % 8: consecutive workgroups go round the XCDs) meet behind every row tile.  They
+    // share their operand slabs through the XCD's L2 - a row slab is read by all workgroups of its slice, a query slab by
+    // all workgroups of its query tile - but only while they are within a few microseconds of each other (the L2 turns over
+    // in about eight), and running free they drift apart by whole folds.  One arrival counter per XCD: a workgroup adds 1
+    // behind each of its tiles and waits until the count reaches (tiles done) x (workgroups of the XCD); a workgroup whose
+    // slice is shorter pays the missing arrivals when it leaves.  The wait is BOUNDED: if the others do not arrive twice in a
+    // row (they are not all resident: another kernel holds CUs), the workgroup stops meeting for the rest of the launch, and
+    // so will the others in their turn - no workgroup ever depends on another for progress.
+    const int XSYNC_POLLS = P.xsync_polls;   // bound of one wait
+    bool meet = P.xsync != nullptr;
+    unsigned* const xctr = P.xsync ? P.xsync + (blockIdx.x & 7) * XSYNC_STRIDE : nullptr;
+    const unsigned xmembers = (unsigned)(nblocks >> 3);
+    const unsigned tiles_max = (unsigned)(P.rows_per_slice / TM);
     // Cross-slice bound in two cheap steps after a fold (tops_bound is a memory round trip and a 64-key sort per query,
     // too much for every slice to do for all 256 queries): one row tile after the fold, when every slice of the
     // query tile has published its tops, this slice computes the bound of ITS share of the queries (ql = slice mod
@@ -246,7 +288,7 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
             // the pieces of the PREVIOUS phase are read from the next phase on.  Every wave's own must have landed before
             // the barrier event that lets group 0 into that phase: group 1 waits here, group 0 behind its MFMAs (one
             // event later in its own sequence, the same event of the workgroup); this phase's four may stay in flight
-            if (wm == 1) { if (issue) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            if (wm == 1) { if (issue) asm volatile(PP_T_WAIT4 ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -263,7 +305,7 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
             __builtin_amdgcn_s_setprio(0);
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            if (wm == 0) { if (issue) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            if (wm == 0) { if (issue) asm volatile(PP_T_WAIT4 ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             __builtin_amdgcn_s_barrier();
         }
 #if SSMI_PP_PRIO == 1
@@ -345,7 +387,25 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
             if (tid == 0) *flag_l = 0;
         }
         STAMP(7)
+        if (xctr) {
+            if (tid == 0) {
+                __hip_atomic_fetch_add(xctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (meet && tiles_done >= (unsigned)P.xsync_from) {
+                    const unsigned target = tiles_done * xmembers;
+                    int polls = 0;
+                    while (__hip_atomic_load(xctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++polls < XSYNC_POLLS) __builtin_amdgcn_s_sleep(8);
+                    // two waits in a row that ran out: the others are not coming
+                    lds_store(flag_l + 1, polls >= XSYNC_POLLS ? flag_l[1] + 1u : 0u);
+                }
+            }
+            if (meet && tiles_done >= (unsigned)P.xsync_from) {
+                __syncthreads();
+                meet = flag_l[1] < 2u;
+            }
+        }
     }
+    // a shorter slice pays the arrivals the others still wait for
+    if (xctr && tid == 0 && tiles_done < tiles_max) __hip_atomic_fetch_add(xctr, tiles_max - tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef SSMI_STAMP
     if (lane == 0 && P.dbg)
         for (int i = 0; i < 8; ++i) P.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = stv[i];

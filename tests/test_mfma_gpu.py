@@ -185,3 +185,38 @@ def test_top1_batches_take_the_argmax_epilogue(ssa, n, d, nq):
     D2, I2 = index.search(Q, 2)                             # and agrees with the first column of the general path
     np.testing.assert_array_equal(I2[:, 0], I[:, 0]); np.testing.assert_array_equal(D2[:, 0], D[:, 0])
     index.close()
+
+
+# ---- the workgroups of an XCD meeting behind every row tile, and XCD patches of query tiles x slices (round 3): neither
+# ---- may change a result.  Forced on here (the plan switches them on from 128 row tiles per slice only); the wait of a
+# ---- meeting is bounded: with a bound of one poll every wait runs out (what happens when the workgroups are not all resident,
+# ---- because another kernel holds CUs), each workgroup stops meeting after two of them, and the launch finishes all the same
+@pytest.mark.parametrize("n,d,nq,k,patch,sync_from,polls", [
+    (300000, 256, 4096, 10, "8", "0", "64"),     # 16 query tiles x 16 slices, 74 row tiles per slice: the bench's mapping
+    (300000, 256, 4096, 100, "4", "17", "64"),   # k = 100 lists, meetings from tile 17 on
+    (200000, 128, 2048, 10, "2", "0", "64"),     # 8 query tiles x 32 slices
+    (150001, 256, 2100, 10, "0", "0", "64"),     # ragged last query tile and last slice shorter than the others (it pays its arrivals)
+    (300000, 256, 4096, 10, "8", "0", "1"),      # every wait runs out at once
+])
+def test_xcd_meetings_and_patches_change_no_result(ssa, monkeypatch, n, d, nq, k, patch, sync_from, polls):
+    X, Q = unit_rows(n, d, 21), unit_rows(nq, d, 22)
+    index = ssa.IndexFlatIP(d, storage="f16")
+    index.add(X)
+    monkeypatch.setenv("SSMI_MFMA_SYNC", "0")
+    monkeypatch.setenv("SSMI_MFMA_PATCH", "0")
+    D0, I0 = index.search(Q, k)
+    assert index.last_kernel() == "flat_mfma_pp_kernel"
+    monkeypatch.setenv("SSMI_MFMA_SYNC", "1")
+    monkeypatch.setenv("SSMI_MFMA_PATCH", patch)
+    monkeypatch.setenv("SSMI_MFMA_SYNC_FROM", sync_from)
+    monkeypatch.setenv("SSMI_MFMA_SYNC_POLLS", polls)
+    for _ in range(2):                                     # twice: the arrival counters are zeroed per launch
+        D1, I1 = index.search(Q, k)
+        np.testing.assert_array_equal(I0, I1)
+        np.testing.assert_array_equal(D0, D1)
+    sel = np.arange(0, nq, max(1, nq // 64))               # and the oracle on a sample of the queries
+    Xh, Qh = r16(X), r16(Q[sel])
+    Dr, Ir = flat_ip.search(Xh, Qh, k)
+    ok, msg, _ = flat_ip.check_against(D1[sel], I1[sel], Dr, Ir, Xh, Qh, rtol=1e-5, tie_rtol=1e-5)
+    assert ok, msg
+    index.close()
