@@ -557,6 +557,21 @@ def run_ivf(args, D, emit=True, with_cpu=True):
 
 
 # --------------------------------------------------------------------------------------------- side measurements
+def kernel_clock(index, tflops):
+    """Shader clock under the last 256-query MFMA launch of `index` (workgroup 0's own s_memtime / s_memrealtime stamps,
+    ssmi_index_get_kernel_clock).  The kernel is power-limited: the same binary holds 1.6-1.9 GHz depending on the box and
+    on its operand traffic, so the fraction of the 2.5 PF peak (quoted at 2.4 GHz) moves with the box; the fraction of the
+    peak AT THE CLOCK THE CHIP HELD is the share of matrix-pipe issue slots the kernel fills, whatever the box."""
+    try:
+        c = index.last_kernel_clock()
+    except RuntimeError:
+        return {}
+    out = {"shader_clock_mhz": c["mhz"], "kernel_cycles_workgroup0": c["cycles"]}
+    if tflops is not None:
+        out["mfma_frac_at_that_clock"] = tflops / (MFMA_F16_PEAK_TFLOPS * c["mhz"] / 2400.0)
+    return out
+
+
 def side_batches(index, local, n_local, args, D, g):
     """Batch 1024 / 4096 over the same (sharded) database: the MFMA contraction (on the fp16 shadow copy when the
     storage is f32), with the recall@k of that path against the exact scan of the stored rows."""
@@ -571,6 +586,7 @@ def side_batches(index, local, n_local, args, D, g):
              "operand_dtype": ("%s (shadow copy of the f32 rows), f32 accumulate" % (local.shadow_dtype or "f16")) if args.storage == "f32"
                               else "%s, f32 accumulate" % args.storage}
         e["mfma_frac_of_2.5PF"] = e["achieved_tflops_per_gpu"] / MFMA_F16_PEAK_TFLOPS
+        e.update(kernel_clock(local, e["achieved_tflops_per_gpu"]))
         if D.world == 1:
             # recall of the batched path against the exact streaming scan (fp32 queries, stored rows as they are)
             _, Ib = index.search(Qb[0], args.k)
@@ -676,10 +692,14 @@ def side_flat_c3(args, D, g):
     for i in range(3):
         c3.search(Q3[i % 2], k)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
+    clk = kernel_clock(c3, None)
     roof = flat_roofline(c3, n, args.d, "f16", B, 3)
     out = {"workload": flat_workload_label(n, args.d, "f16", B, k, 1), "qps": B * 3 / el, "ms_per_step": el / 3 * 1e3,
            "kernel": roof["kernel"], "kernel_avg_ms": roof["kernel_avg_ms"], "achieved_tflops": roof["achieved"],
            "mfma_frac_of_2.5PF": roof["frac"]}
+    if clk:
+        clk["mfma_frac_at_that_clock"] = roof["achieved"] / (MFMA_F16_PEAK_TFLOPS * clk["shader_clock_mhz"] / 2400.0)
+        out.update(clk)
     # recall@100 of the MFMA path (fp16 queries) against the exact scan of the same fp16 rows (fp32 queries)
     _, Ib = c3.search(Q3[0], k)
     sel = torch.arange(0, B, B // 32, device=D.dev)[:32]

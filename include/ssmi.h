@@ -223,6 +223,13 @@ int ssmi_index_get_shadow_dtype(const ssmi_index* h, int* out);
  * owned by the library, "" before the first search (bench.py labels its roofline with it; rocprofv3 traces
  * show the same name). */
 int ssmi_index_get_last_kernel(const ssmi_index* h, const char** out);
+/* The shader clock the chip held under the last search's contraction kernel, when that was the 256-query MFMA kernel
+ * (batches above 128; an error otherwise): workgroup 0 stamps the shader-clock counter and the 100 MHz counter at its
+ * start and its end; cycles / elapsed = MHz.  The kernel is power-limited, so the same binary runs at 1.6-1.9 GHz from
+ * box to box and from operand traffic to operand traffic; bench.py prints the figure next to every MFMA fraction so
+ * that a slow box and a slow kernel can be told apart.  Waits for the handle's stream.  No counterpart in the reference
+ * (measurement plumbing of SURVEY.md 8(d)). */
+int ssmi_index_get_kernel_clock(const ssmi_index* h, double* mhz_out, int64_t* cycles_out, double* ms_out);
 /* Switches the per-search hipEvent triple on (default; env SSMI_TIMING=0 starts with it off) or off.
  * An event record between two kernels costs the stream about 6 us of idle time on this device, three
  * of them 12 % of a batch-1 IVF search, so a serving loop turns it off; get_timing then reports -1 ms

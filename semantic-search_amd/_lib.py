@@ -86,6 +86,7 @@ _SIGNATURES = {
                                     ctypes.POINTER(ctypes.c_int)],
     "ssmi_index_get_shadow_dtype": [_c_index_p, ctypes.POINTER(ctypes.c_int)],
     "ssmi_index_get_last_kernel": [_c_index_p, ctypes.POINTER(ctypes.c_char_p)],
+    "ssmi_index_get_kernel_clock": [_c_index_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)],
     "ssmi_index_set_timing": [_c_index_p, ctypes.c_int],
     "ssmi_index_get_list_sizes": [_c_index_p, ctypes.c_void_p],
     "ssmi_index_get_assignments": [_c_index_p, ctypes.c_void_p],

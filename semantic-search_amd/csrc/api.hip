@@ -430,6 +430,7 @@ static int store_search_mfma(ssmi_index* h, const RowStore& R, int64_t nq, const
     h->timing_valid = true;
     h->timing.last_path = 1;
     h->last_kernel = p.kernel;
+    h->last_clk = p.clk_off ? reinterpret_cast<const unsigned long long*>(static_cast<const unsigned char*>(h->ws[4]) + p.clk_off) : nullptr;
     h->timing.last_grid = p.grid;
     h->timing.last_scan_bytes = (int64_t)R.nrows * R.d * R.elsize;
     h->timing.last_scan_flops = 2ll * std::min<int64_t>(nq, kMaxBatch) * R.nrows * R.d;
@@ -555,6 +556,7 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
     h->timing_valid = true;
     h->timing.last_path = 0;
     h->last_kernel = "flat_scan_topk_kernel";
+    h->last_clk = nullptr;
     h->timing.last_grid = p.grid_x * p.grid_y;
     h->timing.last_scan_bytes = (int64_t)R.nrows * R.d * R.elsize * ((nq + p.bt - 1) / p.bt);
     h->timing.last_scan_flops = 2ll * nq * R.nrows * R.d;
@@ -845,6 +847,23 @@ int ssmi_index_get_last_kernel(const ssmi_index* h, const char** out) {
     return guarded([&]() -> int {
     if (!h || !out) return fail("NULL argument");
     *out = h->last_kernel;
+    return 0;
+    });
+}
+
+int ssmi_index_get_kernel_clock(const ssmi_index* h, double* mhz_out, int64_t* cycles_out, double* ms_out) {
+    return guarded([&]() -> int {
+    if (!h || !mhz_out || !cycles_out || !ms_out) return fail("NULL argument");
+    if (!h->last_clk) return fail("the last search did not run the 256-query MFMA kernel");
+    DeviceGuard g(h->device);
+    unsigned long long st[4];
+    HIPCHECK(hipMemcpyAsync(st, h->last_clk, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (st[1] <= st[3] || st[0] <= st[2]) return fail("no clock stamps yet");
+    const double us = (double)(st[1] - st[3]) / 100.0;   // s_memrealtime ticks at 100 MHz
+    *cycles_out = (int64_t)(st[0] - st[2]);
+    *ms_out = us / 1000.0;
+    *mhz_out = (double)(st[0] - st[2]) / us;
     return 0;
     });
 }

@@ -65,6 +65,7 @@ struct ssmi_index {
     void* ws[ssmi::kWsSlots] = {};
     size_t ws_bytes[ssmi::kWsSlots] = {};
     ssmi_timing timing = {};
+    const unsigned long long* last_clk = nullptr;  // clock stamps of the last 256-query MFMA launch (device), or nullptr
     const char* last_kernel = "";  // name of the dominant kernel of the last search (ssmi_index_get_last_kernel)
     bool timing_valid = false;
     bool timing_on = true;  // record the event triple of every search (ssmi_index_set_timing)

@@ -37,6 +37,7 @@ struct MfmaPlan {
     int q_pitch;  // halves per row of the 16-bit query workspace (ld, or ld + 64 for the 256-query kernel)
     int dtype;    // SSMI_F16 or SSMI_BF16: the rows' type; queries are narrowed to the same type
     size_t qh_bytes, cand_bytes, lds;
+    size_t clk_off;  // 256-query kernel: byte offset of its four clock stamps inside the query workspace (0: none)
     const char* kernel;  // which contraction kernel launch_flat_mfma will run
 };
 bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_cu, MfmaPlan* p);

@@ -88,6 +88,8 @@ bool plan_flat_mfma(int dtype, int ld, long long nrows, int nq, int k, int num_c
     p->q_pitch = p->narrow ? ld : ld + 64;
     p->qh_bytes = (size_t)p->nqt * TN * p->q_pitch * 2 + (size_t)p->nqt * TN * sizeof(unsigned) +
                   (size_t)p->nqt * TN * p->nslices * p->gtop_m * sizeof(unsigned) + 8 * XSYNC_STRIDE * sizeof(unsigned);
+    p->clk_off = 0;
+    if (!p->narrow) { p->qh_bytes = (p->qh_bytes + 7) / 8 * 8; p->clk_off = p->qh_bytes; p->qh_bytes += 4 * sizeof(unsigned long long); }
     p->cand_bytes = (size_t)p->grid * TN * CAND_CAP * sizeof(skey_t);
     const char* env_r = getenv("SSMI_MFMA_R128");
     p->kernel = !p->narrow ? "flat_mfma_pp_kernel"
@@ -122,6 +124,7 @@ hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, con
     P.gtop = share_tops ? gtop : nullptr;
     P.gtop_m = p.gtop_m;
     P.thr_floor = min_ord ? ord_to_f32(min_ord) : SSMI_NEG_MAX;
+    P.clk = p.clk_off ? reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(qh) + p.clk_off) : nullptr;
     { const char* e = getenv("SSMI_MFMA_SEED_FIRST"); P.seed_first = !(e && e[0] == '0'); }
     // scheduled folds after row tiles 1, 4, 16, 64, ... of a slice; with the cross-slice bound (which matures much faster
     // than a slice's own k-th score) after 1, 16, 256, ... only (SSMI_MFMA_FOLD_MASK: bit b = a fold after tile 2^b)

@@ -44,6 +44,9 @@ struct MfmaParams {
     int patch_a;               // 256-query kernel: query tiles per XCD patch (0: an XCD takes whole slices, all query tiles)
     unsigned* xsync;           // 256-query kernel: [8][32] arrival counters, one per XCD (workgroups i % 8), zeroed by the query
                                // conversion; nullptr: the workgroups of an XCD run free
+    // 256-query kernel: {shader clock, 100 MHz clock} at the end and at the start of workgroup 0 (s_memtime / s_memrealtime):
+    // cycles / real time = the clock the chip held under this launch (ssmi_index_get_kernel_clock)
+    unsigned long long* clk;
     int xsync_polls;           // ... bound of one wait, in polls of about a microsecond
     int xsync_from;            // ... they meet from this row tile of their slices on (the first tiles carry the heavy folds)
 #ifdef SSMI_STAMP

@@ -128,6 +128,7 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
         cnt_l[tid] = 0;
         kept_l[tid] = 0;
     }
+    if (tid == 0 && blockIdx.x == 0 && P.clk) { P.clk[2] = __builtin_amdgcn_s_memtime(); P.clk[3] = __builtin_amdgcn_s_memrealtime(); }
     if (tid == 0) { flag_l[0] = 0; flag_l[1] = 0; }   // [0]: a candidate buffer is half full, [1]: meetings in a row that the others did not come to (2: this workgroup has stopped meeting them)
     __syncthreads();
 
@@ -413,6 +414,7 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
 
     // ---- end of slice: fold what is left; the k-list is the partial result ----
     __syncthreads();
+    if (tid == 0 && blockIdx.x == 0 && P.clk) { P.clk[0] = __builtin_amdgcn_s_memtime(); P.clk[1] = __builtin_amdgcn_s_memrealtime(); }
     if constexpr (ARGMAX) {
         skey_t* red = reinterpret_cast<skey_t*>(smem);  // the ring is idle: every wave is past its last fragment read
         skey_t key[4];

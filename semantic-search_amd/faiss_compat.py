@@ -320,6 +320,13 @@ class _IndexBase:
         _lib.check(self._lib.ssmi_index_get_last_kernel(self._handle(), ctypes.byref(out)))
         return (out.value or b"").decode()
 
+    def last_kernel_clock(self) -> dict:
+        """Shader clock under the last search's 256-query MFMA kernel: {"mhz", "cycles", "ms"} (RuntimeError when the last
+        search ran another kernel)."""
+        mhz, cyc, ms = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        _lib.check(self._lib.ssmi_index_get_kernel_clock(self._handle(), ctypes.byref(mhz), ctypes.byref(cyc), ctypes.byref(ms)))
+        return {"mhz": float(mhz.value), "cycles": int(cyc.value), "ms": float(ms.value)}
+
     def set_timing(self, enabled: bool) -> None:
         """Per-search hipEvent records on (default) or off: each costs the stream ~6 us, so serving loops switch them off."""
         _lib.check(self._lib.ssmi_index_set_timing(self._handle(), 1 if enabled else 0))
