@@ -244,7 +244,7 @@ def attach_committed_traffic(roof, args, world):
     counters cannot be read from inside the timed process, so this field is a labelled reference, not a live value."""
     if (args.n, args.d, args.batch, args.storage, world) != (1_000_000, 4096, 1, "f32", 1):
         return
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_flat_f32_1M_b1_pmc.json" % tag)
         try:
             prof = json.load(open(path))
@@ -603,7 +603,7 @@ def side_batches(index, local, n_local, args, D, g):
                                    (local.shadow_dtype or "f16") if args.storage == "f32" else args.storage))
         out["batch_%d" % B] = e
     try:  # counter-based MFMA utilisation of the batch-4096 contraction (committed PMC pass, labelled as such)
-        for tag in ("r02", "r01"):
+        for tag in ("r03", "r02", "r01"):
             path = os.path.join(ROOT, "profiles", "%s_mfma_f16_1M_b4096_pmc.json" % tag)
             if os.path.exists(path):
                 v = next(iter(json.load(open(path))["kernels"].values()))
