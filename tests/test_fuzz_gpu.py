@@ -25,6 +25,14 @@ def r16(a):
     return a.astype(np.float16).astype(np.float32)
 
 
+def rbf16(a):
+    """fp32 -> bf16 (round to nearest even) -> fp32: bf16-valued rows and queries, what the reference's embedder emits
+    (core/model_wrapper.py:201-203).  On them bf16 storage is lossless and every path returns the fp32 oracle's result."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = ((u.astype(np.uint64) + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32) << 16
+    return r.view(np.float32).reshape(np.shape(a))
+
+
 def add_in_pieces(index, X, rng):
     """Rows arrive as the reference delivers them: one bulk add, then ragged small ones (16 at a time and odd tails)."""
     n = len(X)
@@ -45,11 +53,13 @@ def test_flat_sweep(ssa, monkeypatch, seed):
     n = int(rng.choice(ROWS))
     nq = int(rng.choice(BATCHES))
     k = int(rng.choice(KS))
-    storage = str(rng.choice(["f32", "f16"]))
+    storage = str(rng.choice(["f32", "f16", "bf16"]))
     if rng.random() < 0.4:  # small storage segments: rows of one search spread over several of them
         monkeypatch.setenv("SSMI_SEG_SHIFT", str(int(rng.choice([8, 9, 10]))))
     case = f"seed={seed} n={n} d={d} nq={nq} k={k} storage={storage}"
     X, Q = unit_rows(n, d, 5000 + seed), unit_rows(nq, d, 7000 + seed)
+    if storage == "bf16":  # bf16-valued inputs: no rounding anywhere, whatever kernel the shape takes
+        X, Q = rbf16(X), rbf16(Q)
     if rng.random() < 0.3 and n >= 8:  # duplicate rows: ties must come back in ascending id
         X[n // 2:n // 2 + 3] = X[0]
     index = ssa.IndexFlatIP(d, storage=storage)
@@ -65,7 +75,7 @@ def test_flat_sweep(ssa, monkeypatch, seed):
         atol = 6 * 2.0 ** -11 * np.sqrt(2.0 / d)
         ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, X, Q, rtol=1e-3, tie_rtol=1e-3, atol=atol)
     elif path == 1:
-        Qs = r16(Q)
+        Qs = r16(Q) if storage == "f16" else Q
         Dr, Ir = flat_ip.search(Xs, Qs, k)
         ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xs, Qs, rtol=1e-5, tie_rtol=1e-5)
     else:
@@ -88,7 +98,7 @@ def test_ivf_sweep(ssa, monkeypatch, seed):
     nq = int(rng.choice([1, 2, 5, 8, 9, 17, 64, 130, 300]))
     k = int(rng.choice([1, 10, 64, 65, 100, 256, 300]))
     nprobe = int(rng.choice([1, 2, 5, nlist, nlist + 3]))
-    storage = str(rng.choice(["f32", "f16"]))
+    storage = str(rng.choice(["f32", "f16", "bf16"]))
     if rng.random() < 0.4:
         monkeypatch.setenv("SSMI_SEG_SHIFT", str(int(rng.choice([8, 10]))))
     if storage == "f32":
@@ -99,6 +109,8 @@ def test_ivf_sweep(ssa, monkeypatch, seed):
     X = cen[rng.integers(0, len(cen), n)] + 0.6 * unit_rows(n, d, 9100 + seed)
     X = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32)
     Q = unit_rows(nq, d, 9200 + seed)
+    if storage == "bf16":  # bf16-valued vectors, centroids and queries: lossless in bf16 lists
+        X, C, Q = rbf16(X), rbf16(C), rbf16(Q)
     index = ssa.IndexIVFFlat(ssa.IndexFlatIP(d, storage=storage), d, nlist, ssa.METRIC_INNER_PRODUCT, storage=storage)
     index.set_centroids(C)
     add_in_pieces(index, X, rng)
@@ -113,8 +125,8 @@ def test_ivf_sweep(ssa, monkeypatch, seed):
     Xs = r16(X) if storage == "f16" else X
     npr = min(nprobe, nlist)
     kernel = index.last_kernel()
-    mfma = "mfma" in kernel  # list-major matrix-core scan: queries are rounded to fp16 as well
-    Qs = r16(Q) if mfma else Q
+    mfma = "mfma" in kernel  # list-major matrix-core scan: queries are rounded to fp16 as well (bf16 lists: to bf16, which they are)
+    Qs = r16(Q) if (mfma and storage != "bf16") else Q
     # a batch of >= 9 queries ranks the lists with fp16 centroids and queries (matrix-core coarse quantizer): the
     # oracle probes with the same rounded operands
     coarse = dict(C_coarse=r16(C), Q_coarse=r16(Q)) if (nq >= 9 and d % 64 == 0) else {}
@@ -170,10 +182,12 @@ def test_ivf_grow_and_search_walk(ssa, monkeypatch, seed):
     rng = np.random.default_rng(2500 + seed + SALT)
     d = int(rng.choice([64, 512, 1024, 4096]))
     nlist = int(rng.choice([4, 16, 50]))
-    storage = str(rng.choice(["f32", "f16"]))
+    storage = str(rng.choice(["f32", "f16", "bf16"]))
     cen = unit_rows(nlist, d, 2600 + seed)
     pool = cen[rng.integers(0, nlist, 5000)] + 0.6 * unit_rows(5000, d, 2700 + seed)
     pool = (pool / np.linalg.norm(pool, axis=1, keepdims=True)).astype(np.float32)
+    if storage == "bf16":  # bf16-valued vectors, centroids and (below) queries
+        cen, pool = rbf16(cen), rbf16(pool)
     index = ssa.IndexIVFFlat(ssa.IndexFlatIP(d, storage=storage), d, nlist, ssa.METRIC_INNER_PRODUCT, storage=storage)
     index.set_centroids(cen)
     at = 0
@@ -187,14 +201,16 @@ def test_ivf_grow_and_search_walk(ssa, monkeypatch, seed):
         nprobe = int(rng.choice([1, 3, nlist]))
         index.nprobe = nprobe
         Q = unit_rows(nq, d, 2800 + seed * 31 + step)
+        if storage == "bf16":
+            Q = rbf16(Q)
         D, I = index.search(Q, k)
         case = f"seed={seed} step={step} d={d} nlist={nlist} {storage} n={at} nq={nq} k={k} nprobe={nprobe} kernel={index.last_kernel()}"
         labels = index.assignments()
         assert len(labels) == at and index.ntotal == at, case
         X = pool[:at]
         mfma = "mfma" in index.last_kernel()
-        Xs = r16(X) if (storage == "f16" or mfma) else X
-        Qs = r16(Q) if mfma else Q
+        Xs = r16(X) if (storage == "f16" or (mfma and storage == "f32")) else X
+        Qs = r16(Q) if (mfma and storage != "bf16") else Q
         coarse = dict(C_coarse=r16(cen), Q_coarse=r16(Q)) if (nq >= 9 and d % 64 == 0) else {}
         Dr, Ir, _ = ivf_flat.search(Xs, cen, labels, Qs, k, min(nprobe, nlist), **coarse)
         tol = 1e-3 if (mfma and storage == "f32") else 1e-5
