@@ -19,6 +19,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -46,6 +47,8 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="only the bench line itself: no side measurements")
     ap.add_argument("--no-ivf-extra", action="store_true", help="skip the IVF4096 / 10M-row side measurement (configs[3])")
     ap.add_argument("--no-c5", action="store_true", help="--gpus N>1: skip the configs[4] per-GPU-shape side measurement")
+    ap.add_argument("--extra-timeout", type=int, default=420,
+                    help="--gpus N>1: seconds the side measurements may take before the line is printed without the rest (0: no limit)")
     ap.add_argument("--c5-rows", type=int, default=12_500_000, help="rows per GPU of the configs[4] side measurement")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000,
                     help="rows of the database the CPU baseline scans (default: all 1M of configs[1] = 16.4 GB of host RAM; "
@@ -834,6 +837,27 @@ def main():
         except Exception as e:
             extra[name] = {"error": repr(e)}
 
+    # ... nor may one that hangs (a rank that raises inside a collective leaves the others waiting in it): with several
+    # ranks the side measurements run under a watchdog.  When it fires, rank 0 prints the line as it stands - the timed
+    # region is long finished - and every rank leaves without taking part in another collective.
+    emitted = threading.Lock()
+
+    def emit_line():
+        if rank == 0 and emitted.acquire(blocking=False):
+            print(json.dumps(line), flush=True)
+
+    def watchdog_fired():
+        extra["watchdog"] = "side measurements did not finish within %d s: cut off, the line is complete without them" % args.extra_timeout
+        emit_line()
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
+
+    watchdog = None
+    if D.on and not args.no_extra and args.extra_timeout > 0:
+        watchdog = threading.Timer(args.extra_timeout, watchdog_fired)
+        watchdog.daemon = True
+        watchdog.start()
+
     if not args.no_extra:
         guarded("batches", lambda: side_batches(index, index.local, n_local, args, D, g))
         if "error" not in extra["batches"]:
@@ -881,8 +905,9 @@ def main():
                     "probed_bytes_per_query_rank0": iv["roofline"]["algorithmic_bytes_per_launch"], **iv["extra"]}
         guarded("c5_weak_ivf", c5_ivf)
 
-    if rank == 0:
-        print(json.dumps(line), flush=True)
+    if watchdog is not None:
+        watchdog.cancel()
+    emit_line()
     D.close()
 
 
