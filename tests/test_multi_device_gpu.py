@@ -150,3 +150,93 @@ def test_manager_surface_over_several_devices(ssa, tmp_path):
     assert type(multi._faiss_index).__name__ == "MultiDeviceFlatIP"
     assert ids(multi.search(q, 20)) == ids(one.search(q, 20))
     multi.close(); one.close()
+
+
+# ---- seeded walks (SSMI_FUZZ_SALT gives other cases): one index over 1..5 logical shards against the same index on one
+# ---- handle, through ragged adds, searches of every batch class, score floors, read-backs and file round trips into other
+# ---- shard counts
+from conftest import SALT
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_flat_walk_over_logical_shards(ssa, tmp_path, seed):
+    rng = np.random.default_rng(4000 + seed + SALT)
+    d = int(rng.choice([64, 100, 256, 1024, 4096]))
+    storage = str(rng.choice(["f32", "f16", "bf16"]))
+    nsh = int(rng.integers(1, 6))
+    pool = unit_rows(7000 if d <= 1024 else 2500, d, 4100 + seed)
+    multi = ssa.IndexFlatIP(d, storage=storage, devices=[0] * nsh)
+    one = ssa.IndexFlatIP(d, storage=storage)
+    at = 0
+    for step in range(10):
+        grow = min(int(rng.choice([0, 1, 16, 16, 250, 3000])), len(pool) - at)
+        if grow:
+            multi.add(pool[at:at + grow]); one.add(pool[at:at + grow]); at += grow
+        assert multi.ntotal == one.ntotal == at
+        nq = int(rng.choice([1, 3, 9, 70, 300]))
+        k = int(rng.choice([1, 10, 100, 300]))
+        Q = unit_rows(nq, d, 4200 + 31 * seed + step)
+        case = f"seed={seed} step={step} d={d} {storage} shards={nsh} n={at} nq={nq} k={k}"
+        plain = one.search(Q, k)
+        if rng.random() < 0.3 and at > k:
+            floor = float(plain[0][0, min(k, at) // 2])
+            a, b = multi.search(Q, k, min_score=floor), one.search(Q, k, min_score=floor)
+        else:
+            a, b = multi.search(Q, k), plain
+        np.testing.assert_array_equal(a[1], b[1], err_msg=case)
+        np.testing.assert_array_equal(a[0], b[0], err_msg=case)
+        if at:
+            ids = rng.integers(0, at, 9)
+            np.testing.assert_array_equal(multi.reconstruct_batch(ids), one.reconstruct_batch(ids), err_msg=case)
+        if step in (4, 9) and at:
+            p = tmp_path / f"w{seed}_{step}.faiss"
+            ssa.write_index(multi, p)
+            back = ssa.read_index(p, storage=storage, devices=[0] * int(rng.integers(1, 5)))
+            assert back.ntotal == at
+            c = back.search(Q, k)
+            np.testing.assert_array_equal(c[1], plain[1], err_msg=case)
+            back.close()
+    multi.close(); one.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_ivf_walk_over_logical_shards(ssa, tmp_path, monkeypatch, seed):
+    from oracle import flat_ip
+    rng = np.random.default_rng(4500 + seed + SALT)
+    d = int(rng.choice([64, 256, 512, 1024]))
+    nlist = int(rng.choice([3, 16, 50]))
+    storage = str(rng.choice(["f32", "f16"]))
+    nsh = int(rng.integers(1, 5))
+    monkeypatch.setenv("SSMI_NO_SHADOW", "1")           # exact scans on both sides: the two forms may pick different
+    monkeypatch.setenv("SSMI_IVF_LIST_MFMA", "0")       # scan kernels for a batch (a shard holds fewer lists), which differ in summation order only
+    cen = unit_rows(nlist, d, 4600 + seed)
+    pool = cen[rng.integers(0, nlist, 4000)] + 0.6 * unit_rows(4000, d, 4700 + seed)
+    pool = (pool / np.linalg.norm(pool, axis=1, keepdims=True)).astype(np.float32)
+    multi = ssa.IndexIVFFlat(None, d, nlist, ssa.METRIC_INNER_PRODUCT, storage=storage, devices=[0] * nsh)
+    one = ssa.IndexIVFFlat(ssa.IndexFlatIP(d, storage=storage), d, nlist, ssa.METRIC_INNER_PRODUCT, storage=storage)
+    multi.set_centroids(cen); one.set_centroids(cen)
+    Xs = pool.astype(np.float16).astype(np.float32) if storage == "f16" else pool
+    at = 0
+    for step in range(8):
+        grow = min(int(rng.choice([1, 16, 16, 40, 400, 1500])), len(pool) - at)
+        if grow:
+            multi.add(pool[at:at + grow]); one.add(pool[at:at + grow]); at += grow
+        assert multi.ntotal == one.ntotal == at
+        np.testing.assert_array_equal(multi.list_sizes(), one.list_sizes())
+        nq = int(rng.choice([1, 3, 9, 40, 130]))
+        k = int(rng.choice([1, 10, 100]))
+        multi.nprobe = one.nprobe = int(rng.choice([1, 3, nlist]))
+        Q = unit_rows(nq, d, 4800 + 31 * seed + step)
+        case = f"seed={seed} step={step} d={d} nlist={nlist} {storage} shards={nsh} n={at} nq={nq} k={k} nprobe={one.nprobe}"
+        (D, I), (Dr, Ir) = multi.search(Q, k), one.search(Q, k)
+        ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xs[:at], Q, rtol=1e-5, tie_rtol=1e-5, atol=2e-6)
+        assert ok, f"{case}: {msg}"
+    p = tmp_path / f"ivfw{seed}.faiss"
+    ssa.write_index(multi, p)
+    back = ssa.read_index(p, storage=storage, devices=[0] * int(rng.integers(1, 5)))
+    assert back.ntotal == at and back.nprobe == one.nprobe
+    D, I = back.search(Q, k)
+    ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xs[:at], Q, rtol=1e-5, tie_rtol=1e-5, atol=2e-6)
+    assert ok, msg
+    for ix in (multi, one, back):
+        ix.close()

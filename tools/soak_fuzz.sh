@@ -4,7 +4,7 @@
 P="python -u -m pytest -x -q -m gpu --timeout 120 --timeout-method thread"
 for salt in $(seq ${1:-1} ${2:-1}); do
   export SSMI_FUZZ_SALT=$salt
-  for f in fuzz_gpu fuzz_api_gpu fuzz_manager_gpu fuzz_files_gpu zz_no_alloc; do
+  for f in fuzz_gpu fuzz_api_gpu fuzz_manager_gpu fuzz_files_gpu multi_device_gpu zz_no_alloc; do
     timeout -k 10 300 $P tests/test_$f.py > gpurun_out/soak${salt}_$f.log 2>&1 || { echo "salt $salt $f FAILED"; tail -n 40 gpurun_out/soak${salt}_$f.log; exit 1; }
     echo "salt $salt $f: $(tail -n 1 gpurun_out/soak${salt}_$f.log)"
   done
