@@ -52,7 +52,8 @@
 #include <algorithm>
 #endif
 
-// timing-only builds (wrong results): SSMI_PP_HOT bit 0: every X piece reads the same cache-hot addresses, bit 1: every Q piece
+// timing-only builds (wrong results): SSMI_PP_HOT bit 0: every X piece reads the same cache-hot addresses, bit 1: every Q piece,
+// bit 2 / 3: the pieces may land one / two phases late, bit 4: half of the row fragments are read (a third less LDS read traffic)
 #ifndef SSMI_PP_HOT
 #define SSMI_PP_HOT 0
 #endif
@@ -62,6 +63,11 @@
 #define PP_T_WAIT4 "s_waitcnt vmcnt(12)"
 #else
 #define PP_T_WAIT4 "s_waitcnt vmcnt(4)"
+#endif
+#if SSMI_PP_HOT & 16
+#define PP_T_AREADS 4
+#else
+#define PP_T_AREADS 8
 #endif
 #if SSMI_PP_HOT & 1
 #define PP_T_OFFX(x) ((x) & 0u)
@@ -283,7 +289,11 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
             half8_t a[8], b[4];
             const int ao = a_row + (h ? fch1 : fch0), bo = b_row + (h ? fch0 : fch1);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) a[m] = *reinterpret_cast<const half8_t*>(slab_x + ao + m * 16 * 128);
+            for (int m = 0; m < PP_T_AREADS; ++m) a[m] = *reinterpret_cast<const half8_t*>(slab_x + ao + m * 16 * 128);
+#if PP_T_AREADS < 8   // timing-only: a third less fragment traffic (what a 128 x 128 wave tile would read per flop)
+#pragma unroll
+            for (int m = PP_T_AREADS; m < 8; ++m) a[m] = a[m - PP_T_AREADS];
+#endif
 #pragma unroll
             for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const half8_t*>(slab_q + bo + n * 16 * 128);
             // the pieces of the PREVIOUS phase are read from the next phase on.  Every wave's own must have landed before
