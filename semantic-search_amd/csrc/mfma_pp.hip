@@ -53,7 +53,8 @@
 #endif
 
 // timing-only builds (wrong results): SSMI_PP_HOT bit 0: every X piece reads the same cache-hot addresses, bit 1: every Q piece,
-// bit 2 / 3: the pieces may land one / two phases late, bit 4: half of the row fragments are read (a third less LDS read traffic)
+// bit 2 / 3: the pieces may land one / two phases late, bit 4: half of the row fragments are read (a third less LDS read traffic),
+// bit 5: no operand DMA
 #ifndef SSMI_PP_HOT
 #define SSMI_PP_HOT 0
 #endif
@@ -63,6 +64,11 @@
 #define PP_T_WAIT4 "s_waitcnt vmcnt(12)"
 #else
 #define PP_T_WAIT4 "s_waitcnt vmcnt(4)"
+#endif
+#if SSMI_PP_HOT & 32   // no operand DMA at all: fragment reads, MFMAs and the epilogue alone
+#define PP_T_DMA false
+#else
+#define PP_T_DMA true
 #endif
 #if SSMI_PP_HOT & 16
 #define PP_T_AREADS 4
@@ -170,12 +176,12 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
     // the wave's four pieces of an X slab (K offset KOFF bytes into the rows, TOFF more: the next tile) / of a Q slab
     // (OFF bytes into the stored query rows) into ring slot SL
 #define ISSUE_X(SL, KOFF, TOFF)                                                              \
-    {                                                                                        \
+    if (PP_T_DMA) {                                                                          \
         unsigned char* dst_ = smem + (SL) * SLAB + (wave * 4) * 1024;                        \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) GLDS16(asrc[j_] + PP_T_OFFX((TOFF) + (KOFF)), dst_ + j_ * 1024);          \
     }
 #define ISSUE_Q(SL, OFF)                                                                     \
-    {                                                                                        \
+    if (PP_T_DMA) {                                                                          \
         unsigned char* dst_ = smem + QRING + (SL) * SLAB + (wave * 4) * 1024;                \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                \
             GLDS16(qbase + j_ * q_step + (piece_coff ^ ((j_ & 1) << 6)) + PP_T_OFFQ(OFF), dst_ + j_ * 1024);                       \
