@@ -98,6 +98,13 @@ ProgressCallback = Optional[Callable[[int, int, str], None]]
 _TRAIN_SAMPLE_CAP = 100000  # core/index_factory.py:293,401
 
 
+def _approximate_as_flat(config) -> bool:
+    """HNSW / IVF-PQ are outside this engine's scope and fail loudly by default; `IndexConfig.extra["approx_as_flat"]` or
+    SSMI_APPROX_AS_FLAT=1 maps them to the exact Flat index instead."""
+    import os
+    return bool(config.extra.get("approx_as_flat")) or os.environ.get("SSMI_APPROX_AS_FLAT") == "1"
+
+
 class IndexFactory:
     """core/index_factory.py:122-416"""
 
@@ -113,6 +120,12 @@ class IndexFactory:
             index = faiss.IndexIVFFlat(quantizer, config.dimension, config.nlist, faiss.METRIC_INNER_PRODUCT, **opts)
             index.nprobe = config.nprobe
             return index
+        if config.index_type in (IndexType.HNSW, IndexType.IVF_PQ) and _approximate_as_flat(config):
+            # opt-in for a switched-over installation whose UI still offers "hnsw" (nodes/index_nodes.py:34-44): the exact
+            # Flat index returns a superset-quality answer for either approximate type (recall 1.0); the object says what
+            # it is (IndexFlatIP), so detect_index_type and config.json record "flat" from the next save on
+            print(f"[SemanticSearch] index type {config.index_type.value!r} is served by the exact Flat index (SSMI_APPROX_AS_FLAT)")
+            return faiss.IndexFlatIP(config.dimension, **opts)
         if config.index_type in (IndexType.HNSW, IndexType.IVF_PQ):
             raise NotImplementedError(
                 f"index type {config.index_type.value!r} is outside the MI355X engine's scope (flat, ivf_flat)")

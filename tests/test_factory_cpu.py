@@ -90,6 +90,23 @@ def test_out_of_scope_types_fail_loudly(ssa):
         F.create_index(C("bogus", 64))
 
 
+def test_approximate_types_map_to_flat_only_on_request(ssa, monkeypatch):
+    """The opt-in of INTEGRATION.md section 3: no GPU is touched before the mapping is decided."""
+    from semantic_search_amd import index_factory as m
+    F, C, T = ssa.IndexFactory, ssa.IndexConfig, ssa.IndexType
+    made = []
+    monkeypatch.setattr(m.faiss, "IndexFlatIP", lambda d, **kw: made.append((d, kw)) or "flat-index")
+    assert not m._approximate_as_flat(C(T.HNSW, 64))
+    monkeypatch.setenv("SSMI_APPROX_AS_FLAT", "1")
+    assert F.create_index(C(T.HNSW, 64)) == "flat-index" and F.create_index(C(T.IVF_PQ, 32)) == "flat-index"
+    monkeypatch.delenv("SSMI_APPROX_AS_FLAT")
+    cfg = C(T.HNSW, 16); cfg.extra["approx_as_flat"] = True
+    assert F.create_index(cfg) == "flat-index"
+    assert [d for d, _ in made] == [64, 32, 16]
+    with pytest.raises(NotImplementedError):
+        F.create_index(C(T.HNSW, 64))
+
+
 def test_merge_search_results_normalises_dedups_and_sorts(ssa):
     """Mirror of SemanticIndex.merge_search_results (reference core/index_manager.py:635-703)."""
     from semantic_search_amd.index_manager import SearchResult, SearchResults, SemanticIndex
