@@ -128,6 +128,7 @@ int ensure_ws(ssmi_index* h, int slot, size_t bytes) {
     if (h->ws_bytes[slot] >= bytes && h->ws[slot]) return 0;
     // a caller-provided stream may still be using the old buffer: drain the device (rare path)
     if (h->ws[slot]) { HIPCHECK(hipDeviceSynchronize()); HIPCHECK(hipFree(h->ws[slot])); h->ws[slot] = nullptr; h->ws_bytes[slot] = 0; }
+    if (slot == 4) h->last_clk = nullptr;  // the clock stamps of the last MFMA launch lived in the old buffer
     size_t cap = std::max(bytes, (size_t)1 << 20);
     cap = (cap + 255) / 256 * 256;
     HIPCHECK(hipMalloc(&h->ws[slot], cap));
@@ -857,8 +858,12 @@ int ssmi_index_get_kernel_clock(const ssmi_index* h, double* mhz_out, int64_t* c
     if (!h->last_clk) return fail("the last search did not run the 256-query MFMA kernel");
     DeviceGuard g(h->device);
     unsigned long long st[4];
-    HIPCHECK(hipMemcpyAsync(st, h->last_clk, sizeof(st), hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
+    // the search may have run on a caller's stream: wait for that one, then copy
+    if (h->have_last_search && hipStreamSynchronize(h->last_search_stream) != hipSuccess) {
+        (void)hipGetLastError();            // that stream no longer exists
+        HIPCHECK(hipDeviceSynchronize());
+    }
+    HIPCHECK(hipMemcpy(st, h->last_clk, sizeof(st), hipMemcpyDeviceToHost));
     if (st[1] <= st[3] || st[0] <= st[2]) return fail("no clock stamps yet");
     const double us = (double)(st[1] - st[3]) / 100.0;   // s_memrealtime ticks at 100 MHz
     *cycles_out = (int64_t)(st[0] - st[2]);

@@ -220,3 +220,24 @@ def test_xcd_meetings_and_patches_change_no_result(ssa, monkeypatch, n, d, nq, k
     ok, msg, _ = flat_ip.check_against(D1[sel], I1[sel], Dr, Ir, Xh, Qh, rtol=1e-5, tie_rtol=1e-5)
     assert ok, msg
     index.close()
+
+
+def test_kernel_clock_of_the_last_contraction(ssa):
+    """ssmi_index_get_kernel_clock: the 256-query kernel stamps its own start and end (shader clock and the 100 MHz clock);
+    the figure must be a plausible GPU clock, the elapsed time must agree with the hipEvent time of that launch, and a search
+    that ran another kernel must say so."""
+    d = 512
+    index = ssa.IndexFlatIP(d, storage="f16")
+    index.add(unit_rows(200000, d, 31))
+    with pytest.raises(RuntimeError):
+        index.last_kernel_clock()                      # no search yet
+    index.search(unit_rows(600, d, 32), 10)
+    assert index.last_kernel() == "flat_mfma_pp_kernel"
+    c = index.last_kernel_clock()
+    assert 500.0 < c["mhz"] < 3000.0 and c["cycles"] > 0
+    ms = index.last_timing()["last_scan_ms"]
+    assert 0.3 * ms < c["ms"] <= 1.1 * ms, (c, ms)     # workgroup 0 starts with the launch and ends with its own slice
+    index.search(unit_rows(2, d, 33), 10)               # the streaming scan
+    with pytest.raises(RuntimeError):
+        index.last_kernel_clock()
+    index.close()
