@@ -619,6 +619,20 @@ def side_batches(index, local, n_local, args, D, g):
     return out
 
 
+def side_small_batches(index, local, n_local, args, D, g):
+    """2 / 4 / 8 queries per search over the bench's database: the exact streaming scan (K1 below five queries on
+    fp32 rows of 8 KiB and more, K1m - the same scan with its multiply-adds on the fp32 matrix instruction - for 5-8),
+    the batch sizes the reference's multi-index and exclusion flows issue (nodes/search_nodes.py:869-878)."""
+    out = {}
+    for B in (2, 4, 8):
+        Qb = unit_queries(g, (2, B, args.d), D.dev)
+        el = D.timed(lambda i: index.search(Qb[i % 2], args.k), 20, 2)
+        roof = flat_roofline(local, n_local, args.d, args.storage, B, 20)
+        out["batch_%d" % B] = {"qps": B * 20 / el, "ms_per_step": el / 20 * 1e3, "kernel": roof["kernel"], "kernel_avg_ms": roof["kernel_avg_ms"],
+                               "hbm_frac": roof["frac"] if roof["bound"] == "hbm" else None, "bound": roof["bound"]}
+    return out
+
+
 def add_same_unit_rows(indexes, n, d, dev, seed, bf16_valued=False):
     """The same device-generated unit rows (N(0,1) components, L2-normalised) appended to every index of the
     list, through the product's own add() (16-bit storage rounds to nearest even there).  bf16_valued: the rows are
@@ -860,6 +874,7 @@ def main():
 
     if not args.no_extra:
         guarded("batches", lambda: side_batches(index, index.local, n_local, args, D, g))
+        guarded("small_batches", lambda: side_small_batches(index, index.local, n_local, args, D, g))
         if "error" not in extra["batches"]:
             extra.update(extra.pop("batches"))
     if rank == 0 and not args.no_cpu_baseline and world == 1:

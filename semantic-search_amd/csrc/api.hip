@@ -556,7 +556,7 @@ int store_search(ssmi_index* h, const RowStore& R, int64_t nq, const float* qdev
     h->events_valid = h->timing_on;
     h->timing_valid = true;
     h->timing.last_path = 0;
-    h->last_kernel = "flat_scan_topk_kernel";
+    h->last_kernel = p.mm ? "flat_scan_mm_kernel" : "flat_scan_topk_kernel";
     h->last_clk = nullptr;
     h->timing.last_grid = p.grid_x * p.grid_y;
     h->timing.last_scan_bytes = (int64_t)R.nrows * R.d * R.elsize * ((nq + p.bt - 1) / p.bt);

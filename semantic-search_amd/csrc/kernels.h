@@ -11,6 +11,8 @@ struct ScanPlan {
     int nch;       // static chunks per row (0 = runtime loop)
     bool qreg;     // query in registers
     bool nt;       // non-temporal row loads
+    bool mm;       // K1m (scan_mm.h): four rows per wave pass, multiply-adds on the matrix pipe
+    int mm_g;      // K1m: 16-byte loads per lane and half stage (8 or 4)
     int threads;
     int grid_x;    // row slices == partial lists per query
     int grid_y;    // query tiles

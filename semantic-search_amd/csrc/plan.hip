@@ -64,12 +64,52 @@ bool plan_flat_scan(int dtype, int ld, long long nrows, int nq, int k, int num_c
             blocks_per_cu = 1;
         }
     }
+    // K1m (scan_mm.h): four rows per wave pass, multiply-adds on the matrix pipe, queries in quads
+    p->mm = false;
+    p->mm_g = 0;
+    {
+        const char* e = getenv("SSMI_SCAN_MM");  // 0: never; 1: every shape it can take; 1a: also 1-2 queries (as a quad); unset: the policy below
+        const int mm_nch = ld / (16 * V);        // 256-byte chunks per row
+        int mm_g = 0;                            // loads per lane and half stage: the largest that divides half a row
+        if ((ld % (16 * V)) == 0)
+            for (int g = 16; g >= 1 && !mm_g; g >>= 1) if (mm_nch % (2 * g) == 0) mm_g = g;
+        if (const char* eg = getenv("SSMI_MM_G")) {  // experiments
+            const int v = atoi(eg);
+            if ((v == 1 || v == 2 || v == 4 || v == 8 || v == 16) && mm_nch % (2 * v) == 0) mm_g = v;
+        }
+        const size_t row_bytes = (size_t)ld * (dtype == 0 ? 4 : 2);
+        const bool short_rows = row_bytes < 8192;
+        // Policy, measured at 8-16 GB of rows per shape (tools/time_env_ab.py).  Ahead of the register-FMA
+        // form: 5-8 queries and 3-4 queries on 16-bit rows at every row length (1M x 4096 fp32 x 8: 2.54 -> 2.44 ms; 4M x 1024
+        // fp32 x 8: 3.99 -> 2.48 ms; 4M x 512 fp16 x 4: 1.76 -> 0.79 ms); 2-4 queries on rows under 8 KiB (one or two queries run
+        // as a quad: the matrix pipe has the time); one query on rows under 2 KiB (8M x 256 fp32: 1.82 -> 1.29 ms).  Behind
+        // it: 1-4 queries on fp32 rows and 1-2 on 16-bit rows of 8 KiB and more, where the 8-wave register-FMA form holds
+        // 0.87 of the HBM rate and this one 0.85.
+        int mm_bt = bt;
+        bool want = bt == 8 || (bt == 4 && (dtype != 0 || short_rows));
+        if (bt_cap >= 4 && ((bt == 2 && short_rows) || (bt == 1 && row_bytes < 2048))) { want = true; mm_bt = 4; }
+        if (e) {
+            want = e[0] == '1';
+            if (e[0] == '1' && e[1] == 'a' && bt < 4 && bt_cap >= 4) mm_bt = 4;
+            else if (bt < 4) mm_bt = bt;
+        }
+        if (want && !p->qreg && mm_g > 0 && (mm_bt == 4 || mm_bt == 8) && (size_t)mm_bt * ld * 4 <= 128 * 1024) {
+            p->mm = true;
+            p->mm_g = mm_g;
+            p->bt = bt = mm_bt;
+            p->threads = mm_g <= 8 ? 1024 : 512;
+            const size_t qbytes = (size_t)bt * ld * 4, mbytes = (size_t)(p->threads / 64) * kp * sizeof(skey_t);
+            p->lds = qbytes > mbytes ? qbytes : mbytes;
+            blocks_per_cu = 1;
+        }
+    }
     const char* env_bpc = getenv("SSMI_SCAN_BPC");
     if (env_bpc) { int v = atoi(env_bpc); if (v >= 1 && v <= 16) blocks_per_cu = v; }
     const int nwaves = p->threads / 64;
     long long gx = (long long)num_cu * blocks_per_cu;
     int min_rows = 1;  // rows per wave below which more blocks only add partial lists (the merge thins them cheaply)
     if (const char* e = getenv("SSMI_SCAN_MINROWS")) { const int v = atoi(e); if (v >= 1 && v <= 64) min_rows = v; }
+    if (p->mm) min_rows *= 4;  // a wave pass is four rows
     const long long max_useful = (nrows + (long long)nwaves * min_rows - 1) / ((long long)nwaves * min_rows);
     if (gx > max_useful) gx = max_useful;
     if (gx < 1) gx = 1;

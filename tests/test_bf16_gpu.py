@@ -43,8 +43,9 @@ def exact(ssa, index, Xv, Qv, k, path=None, kernel=None, min_score=None):
 # ------------------------------------------------------------------------------------------------- Flat
 @pytest.mark.parametrize("n,d,nq,k,kernel", [
     (20000, 4096, 1, 10, "flat_scan_topk_kernel"),        # K1, query in registers
-    (20000, 4096, 3, 10, "flat_scan_topk_kernel"),        # K1, queries in LDS
-    (5000, 2048, 4, 100, "flat_scan_topk_kernel"),
+    (20000, 4096, 2, 10, "flat_scan_topk_kernel"),        # K1, queries in LDS
+    (20000, 4096, 3, 10, "flat_scan_mm_kernel"),          # K1m: 3-4 queries on 16-bit rows of whole 8 KiB
+    (5000, 2048, 4, 100, "flat_scan_mm_kernel"),
     (3000, 100, 7, 10, "flat_scan_topk_kernel"),          # d not a multiple of 64: always the scan
     (20000, 4096, 5, 10, "flat_mfma_r128_kernel"),        # K2r, 16-query form
     (20000, 4096, 40, 10, "flat_mfma_r128_kernel"),       # 64-query form

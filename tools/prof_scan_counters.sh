@@ -2,7 +2,8 @@
 # Runs ON THE GPU BOX: what bounds K1 at the batch sizes below its best (5-8 queries on fp32 rows, 3-4 on fp16 rows)?
 # LDS, VALU and memory counters per launch, one rocprofv3 pass per counter group and shape.
 export TMPDIR=/tmp
-for shape in "f32 1" "f32 4" "f32 8" "f16 2" "f16 4"; do
+IFS=";" read -ra LIST <<< "${SHAPES:-f32 1;f32 4;f32 8;f16 2;f16 4}"   # SHAPES="f32 8;f16 4" picks; SSMI_SCAN_MM=0 in the environment keeps K1m out
+for shape in "${LIST[@]}"; do
   set -- $shape
   for grp in "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM"; do
     d=gpurun_out/scanpmc_$1_$2_$(echo $grp | cut -c1-12 | tr ' ' _)
@@ -13,7 +14,7 @@ d, name = sys.argv[1], sys.argv[2]
 f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if "flat_scan_topk" in r["Kernel_Name"]:
+    if "flat_scan_" in r["Kernel_Name"]:   # K1 (flat_scan_topk_kernel) or K1m (flat_scan_mm_kernel)
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 print(name, {k: round(sum(v) / len(v)) for k, v in acc.items()})
 P

@@ -26,7 +26,10 @@ for rnd in range(2):
         ms = ix.scan_times_ms(iters)
         if ref is None:
             ref = (D.clone(), I.clone())
-        assert torch.equal(ref[0], D) and torch.equal(ref[1], I), "variant changes the result"
+        if os.environ.get("SSMI_AB_LOOSE"):  # variants that sum in another order: same ids, scores to 1e-5
+            assert torch.equal(ref[1], I) and torch.allclose(ref[0], D, rtol=1e-5, atol=1e-6), "variant changes the result"
+        else:
+            assert torch.equal(ref[0], D) and torch.equal(ref[1], I), "variant changes the result"
         print("n=%d %s nq=%d k=%d round %d %s: %s mean %.3f ms min %.3f -> %.2f TB/s (%.3f of 8), %.0f TFLOP/s (%.3f of 2500)" % (
             n, storage, nq, k, rnd, " ".join("%s=%s" % (nm, v) for (nm, _), v in zip(variants, combo)), ix.last_kernel(), ms.mean(), ms.min(),
             n * d * el / ms.mean() / 1e9, n * d * el / ms.mean() / 8e9, 2.0 * nq * n * d / ms.mean() / 1e9, 2.0 * nq * n * d / ms.mean() / 1e9 / 2500), flush=True)
