@@ -123,3 +123,8 @@ pmc("mfma_f16_1M_b4096", [f"prof_{tag}_mfma_pmc_sq", f"prof_{tag}_mfma_pmc_lds",
 pmc("ivf_f16_2M_b1", [f"prof_{tag}_ivf_pmc_FETCH_SIZE", f"prof_{tag}_ivf_pmc_WRITE_SIZE"],
     "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate runs) -- python3 tools/prof_ivf.py 2000000 4096 1024 16",
     "IVF1024 nprobe=16 over 2000000x4096 f16, batch 1, k=10", ["ivf_scan_qreg_kernel", "ivf_scan_topk_kernel", "flat_scan_topk_kernel", "ivf_plan_kernel"])
+# K1m (round 3): profiles/collect_scan_mm.sh
+stats("scan_mm_b8", f"prof_{tag}_mm_stats", f"prof_{tag}_mm_stats.log", "flat_scan_mm_kernel")
+pmc("scan_mm_f32_1M_b8", [f"prof_{tag}_mm_pmc_FETCH_SIZE", f"prof_{tag}_mm_pmc_WRITE_SIZE", f"prof_{tag}_mm_pmc_lds", f"prof_{tag}_mm_pmc_valu"],
+    "rocprofv3 --pmc <group> (separate runs) -- python3 bench.py --batch 8 --steps 30 --warmup 3 --no-cpu-baseline --no-extra",
+    "Flat IP 1000000x4096 f32: 8 queries per search, k=10 (flat_scan_mm_kernel)", ["flat_scan_mm_kernel"])

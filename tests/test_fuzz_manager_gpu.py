@@ -48,6 +48,14 @@ def check_search(si, model, q, k, min_score=0.0):
         diff = set(got) ^ set(ids)
         assert all(abs(s[i] - min_score) < 1e-5 for i in diff), (got, ids)
         return
+    if got != ids and len(got) == len(ids) and min_score <= 0:
+        # two rows whose scores differ by less than the fp32 sums' rounding may come out in either order (or, at rank k,
+        # either one): position by position the model's score of the returned id must equal that of the expected one
+        full = model.stored() @ q.astype(np.float32)
+        assert all(model.paths[g] is not None and abs(float(full[g]) - float(full[i])) <= 2e-6 for g, i in zip(got, ids)), \
+            f"ids {got} != model {ids}"
+        np.testing.assert_allclose([r.score for r in res], scores, rtol=1e-5, atol=1e-6)
+        return
     assert got == ids, f"ids {got} != model {ids}"
     np.testing.assert_allclose([r.score for r in res], scores, rtol=1e-5, atol=1e-6)
     assert [r.file_path for r in res] == [model.paths[i] for i in ids]
