@@ -20,6 +20,18 @@ namespace ssmi {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+// a[lane] + a[lane ^ 32] in the lower half of the wave, the same of b in the upper half: v_permlane32_swap hands the upper
+// half of a and the lower half of b to each other, so two registers are folded over one lane bit by one swap and one add
+__device__ __forceinline__ float fold32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(a), __float_as_int(b), false, false);
+    return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+// the same over lane bit 4: a in the even rows of 16 lanes, b in the odd ones
+__device__ __forceinline__ float fold16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(a), __float_as_int(b), false, false);
+    return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+
 // LDS float index of element `elem` of local query `ql` (BT queries per pass, V elements per 16 bytes of row)
 template <int V, int BT>
 __device__ __forceinline__ int qmm_lds_index(int ql, int elem) {
@@ -57,6 +69,9 @@ __global__ void __launch_bounds__(G <= 8 ? 1024 : 512) flat_scan_mm_kernel(RowVi
     const skey_t thr_floor = floor_key(tail.min_ord);
 #pragma unroll
     for (int b = 0; b < BT; ++b) { top[b].init(); thr[b] = thr_floor; }
+    // per-lane float gate: the score below which a candidate of the lane's query (see the fold below) cannot pass thr - the
+    // score field of the threshold key; key 0 decodes to a NaN, against which nothing is "below"
+    float gate = ord_to_f32((uint32_t)(thr_floor >> 32));
 
     // row groups -> waves: the front sweep of K1 (scan_impl.h), in units of four rows
     const unsigned vb = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
@@ -129,29 +144,45 @@ __global__ void __launch_bounds__(G <= 8 ? 1024 : 512) flat_scan_mm_kernel(RowVi
             consume(xb, c0 + G);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // register i of lane 4b+j holds block b's share of <row i, query j>: add the 16 blocks
-#pragma unroll
-        for (int qq = 0; qq < QQ; ++qq) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = acc[qq][i];
-                v += __int_as_float(xor_lane<32>(__float_as_int(v)));
-                v += __int_as_float(xor_lane<16>(__float_as_int(v)));
-                v += __int_as_float(xor_lane<8>(__float_as_int(v)));
-                v += __int_as_float(xor_lane<4>(__float_as_int(v)));
-                acc[qq][i] = v;
-            }
+        // Register i of lane 4b+j holds block b's share of <row i, query quad's j>: the 16 blocks (lane bits 2-5) are summed.
+        // Bits 5 and 4 are folded together with a halving of the registers (fold32 / fold16), bits 3 and 2 with DPP adds:
+        // 8 queries: w[t] of lane (q5, i4, *, *, j) = score of row t + 2*i4, query 4*q5 + j;
+        // 4 queries: w[0] of lane (i5, i4, *, *, j) = score of row 2*i5 + i4, query j
+        float w[QQ];
+        if constexpr (QQ == 2) {
+            const float u0 = fold32(acc[0][0], acc[1][0]), u1 = fold32(acc[0][1], acc[1][1]);
+            const float u2 = fold32(acc[0][2], acc[1][2]), u3 = fold32(acc[0][3], acc[1][3]);
+            w[0] = fold16(u0, u2);
+            w[1] = fold16(u1, u3);
+        } else {
+            const float u0 = fold32(acc[0][0], acc[0][2]), u1 = fold32(acc[0][1], acc[0][3]);
+            w[0] = fold16(u0, u1);
         }
 #pragma unroll
-        for (int b = 0; b < BT; ++b) {
+        for (int t = 0; t < QQ; ++t) {
+            w[t] += __int_as_float(xor_lane<8>(__float_as_int(w[t])));
+            w[t] += __int_as_float(xor_lane<4>(__float_as_int(w[t])));
+        }
+        // one vector compare per score against the lanes' gates: a group without a candidate (nearly all of them once the
+        // lists are warm) costs QQ compares and one branch instead of 4*BT scalar key compares
+        bool cand = !(w[0] < gate);
+        if constexpr (QQ == 2) cand |= !(w[1] < gate);
+        if (__builtin_amdgcn_ballot_w64(cand) != 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc[b / 4][i]), b & 3));
-                const long long row = row0 + i;
-                const skey_t key = make_key(s, (uint32_t)row);
-                if (row < X.nrows && key > thr[b]) {
-                    top[b].insert(key);
-                    thr[b] = kmax(top[b].kth(k), thr_floor);
+            for (int b = 0; b < BT; ++b) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int src = QQ == 2 ? ((b >> 2) << 5) | ((i >> 1) << 4) | (b & 3) : ((i >> 1) << 5) | ((i & 1) << 4) | (b & 3);
+                    const float s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[QQ == 2 ? (i & 1) : 0]), src));
+                    const long long row = row0 + i;
+                    const skey_t key = make_key(s, (uint32_t)row);
+                    if (row < X.nrows && key > thr[b]) {
+                        top[b].insert(key);
+                        thr[b] = kmax(top[b].kth(k), thr_floor);
+                        const float gnew = ord_to_f32((uint32_t)(thr[b] >> 32));
+                        const bool mine = (lane & 3) == (b & 3) && (QQ == 1 || (lane >> 5) == (b >> 2));
+                        gate = mine ? gnew : gate;
+                    }
                 }
             }
         }
