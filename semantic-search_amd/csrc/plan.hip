@@ -82,12 +82,13 @@ bool plan_flat_scan(int dtype, int ld, long long nrows, int nq, int k, int num_c
         // Policy, measured at 8-16 GB of rows per shape (tools/time_env_ab.py).  Ahead of the register-FMA
         // form: 5-8 queries and 3-4 queries on 16-bit rows at every row length (1M x 4096 fp32 x 8: 2.54 -> 2.44 ms; 4M x 1024
         // fp32 x 8: 3.99 -> 2.48 ms; 4M x 512 fp16 x 4: 1.76 -> 0.79 ms); 2-4 queries on rows under 8 KiB (one or two queries run
-        // as a quad: the matrix pipe has the time); one query on rows under 2 KiB (8M x 256 fp32: 1.82 -> 1.29 ms).  Behind
-        // it: 1-4 queries on fp32 rows and 1-2 on 16-bit rows of 8 KiB and more, where the 8-wave register-FMA form holds
-        // 0.87 of the HBM rate and this one 0.85.
+        // as a quad: the matrix pipe has the time); one query wherever the register-query form of K1 does not apply (rows
+        // other than 1/2/4/8/16 KiB: 8M x 256 fp32 1.82 -> 1.29 ms, 512 / 1536 / 3072-d +2-4 %, 768-d equal).  Behind it:
+        // 2-4 queries on fp32 rows and 2 on 16-bit rows of 8 KiB and more, where the 8-wave register-FMA form holds 0.87 of the
+        // HBM rate and this one 0.85.
         int mm_bt = bt;
         bool want = bt == 8 || (bt == 4 && (dtype != 0 || short_rows));
-        if (bt_cap >= 4 && ((bt == 2 && short_rows) || (bt == 1 && row_bytes < 2048))) { want = true; mm_bt = 4; }
+        if (bt_cap >= 4 && ((bt == 2 && short_rows) || bt == 1)) { want = true; mm_bt = 4; }
         if (e) {
             want = e[0] == '1';
             if (e[0] == '1' && e[1] == 'a' && bt < 4 && bt_cap >= 4) mm_bt = 4;

@@ -25,6 +25,8 @@ def _rounded(X, storage):
     (8000, 256, 1, 10, "f32"),       # one query on 1 KiB rows runs as a quad (three copies of it)
     (8000, 512, 2, 10, "f32"),       # two queries on rows under 8 KiB likewise
     (6000, 512, 1, 10, "f16"),
+    (4000, 1536, 1, 10, "f32"),      # one query on a row length K1's register-query form does not take
+    (3000, 3072, 1, 100, "f32"),
     (5000, 768, 8, 10, "f32"),       # 12 chunks per row: two loads per half stage
     (5000, 384, 5, 10, "f32"),       # 6 chunks: one load per half stage
     (4000, 1536, 3, 100, "f32"),     # k = 100 on short fp32 rows
