@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--storage", default="f32", choices=["f32", "f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="only the bench line itself: no side measurements")
+    ap.add_argument("--no-live-traffic", action="store_true", help="keep the committed HBM-traffic figure instead of two rocprofv3 --pmc passes of this command")
     ap.add_argument("--no-ivf-extra", action="store_true", help="skip the IVF4096 / 10M-row side measurement (configs[3])")
     ap.add_argument("--no-c5", action="store_true", help="--gpus N>1: skip the configs[4] per-GPU-shape side measurement")
     ap.add_argument("--extra-timeout", type=int, default=420,
@@ -244,7 +245,8 @@ def flat_roofline(local, n_local, d, storage, batch, launches):
 
 def attach_committed_traffic(roof, args, world):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this exact workload (profiles/collect.sh);
-    counters cannot be read from inside the timed process, so this field is a labelled reference, not a live value."""
+    counters cannot be read from inside the timed process: this is the fallback for live_traffic() below, which measures
+    the same figure with two child processes of this command under the profiler."""
     if (args.n, args.d, args.batch, args.storage, world) != (1_000_000, 4096, 1, "f32", 1):
         return
     for tag in ("r03", "r02", "r01"):
@@ -259,6 +261,52 @@ def attach_committed_traffic(roof, args, world):
                     return
         except Exception:
             continue
+
+
+def live_traffic(args, kernel):
+    """HBM bytes per launch of `kernel`, measured by THIS run: two child processes of the same command (this file with
+    --no-extra, fewer steps) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` - one counter per pass, no trace
+    domain beside it, the program itself behind `--`, as MI355X_MICROARCH.md prescribes - and the corrected sum
+    FETCH_SIZE*1024*2 + WRITE_SIZE*1024 of the kernel's launches.  Each pass runs in a process group of its own under a time
+    limit; whatever goes wrong returns None and the line keeps the committed figure."""
+    import csv, glob, shutil, signal, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="ssmi_pmc_", dir="/tmp")
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--output-format", "csv", "--pmc", ctr, "-d", os.path.join(tmp, ctr), "-o", "b", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "2", "--no-extra", "--no-cpu-baseline",
+                   "--n", str(args.n), "--d", str(args.d), "--k", str(args.k), "--batch", str(args.batch), "--storage", args.storage]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(v, None)
+            p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, start_new_session=True)
+            try:
+                rc = p.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)   # the group this call started, nothing else
+                except Exception:
+                    pass
+                return None
+            if rc != 0:
+                return None
+            got = []
+            for f in glob.glob(os.path.join(tmp, ctr, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if kernel in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                        got.append(float(r["Counter_Value"]))
+            if len(got) < 5:
+                return None
+            vals[ctr] = (sum(got) / len(got), len(got))
+        return {"bytes": vals["FETCH_SIZE"][0] * 1024 * 2 + vals["WRITE_SIZE"][0] * 1024, "launches": vals["FETCH_SIZE"][1]}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def cpu_model():
@@ -872,6 +920,19 @@ def main():
         watchdog.daemon = True
         watchdog.start()
 
+    if not args.no_extra and not args.no_live_traffic and world == 1 and rank == 0:
+        # roofline.traffic from a PMC pass of this very command instead of the committed figure (which stays as the fallback)
+        try:
+            lt = live_traffic(args, roof["kernel"])
+        except Exception:
+            lt = None
+        if lt:
+            if roof.get("traffic") is not None:
+                roof["traffic_committed"] = roof["traffic"]
+            roof["traffic"] = lt["bytes"]
+            roof["traffic_source"] = ("measured by this run: child processes of the same command under rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE "
+                                      "(separate passes), mean over %d launches of %s, FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024"
+                                      % (lt["launches"], roof["kernel"]))
     if not args.no_extra:
         guarded("batches", lambda: side_batches(index, index.local, n_local, args, D, g))
         guarded("small_batches", lambda: side_small_batches(index, index.local, n_local, args, D, g))
