@@ -273,6 +273,8 @@ def live_traffic(args, kernel):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None  # this process is itself being profiled: no profiler inside a profiler
     tmp = tempfile.mkdtemp(prefix="ssmi_pmc_", dir="/tmp")
     vals = {}
     try:
