@@ -21,25 +21,31 @@ def _rounded(X, storage):
     return X
 
 
-@pytest.mark.parametrize("n,d,nq,k,storage", [
-    (8000, 256, 1, 10, "f32"),       # one query on 1 KiB rows runs as a quad (three copies of it)
-    (8000, 512, 2, 10, "f32"),       # two queries on rows under 8 KiB likewise
-    (6000, 512, 1, 10, "f16"),
-    (4000, 1536, 1, 10, "f32"),      # one query on a row length K1's register-query form does not take
-    (3000, 3072, 1, 100, "f32"),
-    (5000, 768, 8, 10, "f32"),       # 12 chunks per row: two loads per half stage
-    (5000, 384, 5, 10, "f32"),       # 6 chunks: one load per half stage
-    (4000, 1536, 3, 100, "f32"),     # k = 100 on short fp32 rows
-    (4000, 2048, 3, 10, "bf16"),
+@pytest.mark.parametrize("n,d,nq,k,storage,kernel", [
+    (8000, 256, 1, 10, "f32", "flat_scan_mm_kernel"),    # one query on 1 KiB rows runs as a quad (three copies of it)
+    (8000, 512, 2, 10, "f32", "flat_scan_mm_kernel"),    # 2 KiB rows
+    (6000, 512, 1, 10, "f16", "flat_scan_mm_kernel"),
+    (5000, 384, 5, 10, "f32", "flat_scan_mm_kernel"),    # 6 chunks of 256 bytes: one load per half stage
+    (4099, 256, 8, 64, "f32", "flat_scan_mm_kernel"),    # last group holds three rows; k = 64 fills the per-wave list
+    (5, 512, 3, 10, "f32", "flat_scan_mm_kernel"),       # fewer rows than one group, fewer than k
+    (7000, 1024, 4, 100, "f16", "flat_scan_mm_kernel"),  # k = 100: two list registers per lane
+    (9001, 256, 3, 10, "bf16", "flat_scan_mm_kernel"),   # 512-byte rows
+    (6000, 256, 20, 10, "f32", "flat_scan_mm_kernel"),   # three query tiles (the shadow is off below)
+    (5000, 768, 8, 10, "f32", "flat_scan_mm_kernel"),      # 3 KiB rows: the four-row form, two loads per half stage
+    (4000, 1536, 3, 100, "f32", "flat_scan_mm_kernel"),    # k = 100 on fp32 rows under 8 KiB
+    (4000, 2048, 3, 10, "bf16", "flat_scan_mm_kernel"),
+    (4000, 1536, 1, 10, "f32", "flat_scan_mm_kernel"),     # one query on a row length K1's register-query form does not take
+    (3000, 3072, 1, 100, "f32", "flat_scan_mm_kernel"),
 ])
-def test_scan_mm_is_what_the_plan_picks(ssa, monkeypatch, n, d, nq, k, storage):
-    """No switches: the shapes plan_flat_scan gives to K1m by itself (csrc/plan.hip)."""
+def test_scan_mm_is_what_the_plan_picks(ssa, monkeypatch, n, d, nq, k, storage, kernel):
+    """No kernel switches: the shapes plan_flat_scan gives to K1m by itself (csrc/plan.hip)."""
     monkeypatch.setenv("SSMI_MFMA_MIN_B", "100000")
+    monkeypatch.setenv("SSMI_NO_SHADOW", "1")
     X, Q = unit_rows(n, d, 1234), unit_rows(nq, d, 4321)
     index = ssa.IndexFlatIP(d, storage=storage)
     index.add(X)
     D, I = index.search(Q, k)
-    assert index.last_kernel() == "flat_scan_mm_kernel", index.last_kernel()
+    assert index.last_kernel() == kernel, index.last_kernel()
     Xr = _rounded(X, storage)
     Dr, Ir = flat_ip.search(Xr, Q, k)
     ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, Xr, Q, rtol=RTOL, tie_rtol=RTOL)
@@ -77,19 +83,19 @@ def test_scan_mm_matches_oracle(ssa, monkeypatch, n, d, nq, k, storage):
     index.close()
 
 
-def test_scan_mm_over_segments_with_a_score_floor(ssa, monkeypatch):
+@pytest.mark.parametrize("d,kernel", [(1024, "flat_scan_mm_kernel"), (512, "flat_scan_mm_kernel")])
+def test_scan_mm_over_segments_with_a_score_floor(ssa, monkeypatch, d, kernel):
     """Rows spread over many small segments (a row group never straddles two: segments hold a multiple of 256 rows),
     and a min_score floor applied in the epilogue."""
-    monkeypatch.setenv("SSMI_SCAN_MM", "1")
     monkeypatch.setenv("SSMI_NO_SHADOW", "1")
     monkeypatch.setenv("SSMI_SEG_SHIFT", "8")
-    n, d, nq, k = 3000, 1024, 8, 20
+    n, nq, k = 3000, 8, 20
     X, Q = unit_rows(n, d, 77), unit_rows(nq, d, 78)
     index = ssa.IndexFlatIP(d)
     for s in range(0, n, 700):
         index.add(X[s:s + 700])
     D, I = index.search(Q, k)
-    assert index.last_kernel() == "flat_scan_mm_kernel"
+    assert index.last_kernel() == kernel
     Dr, Ir = flat_ip.search(X, Q, k)
     ok, msg, _ = flat_ip.check_against(D, I, Dr, Ir, X, Q, rtol=RTOL, tie_rtol=RTOL)
     assert ok, msg
