@@ -140,6 +140,10 @@ hipError_t launch_flat_mfma(const RowView& X, const float* Q, int nq, int k, con
     bool meet_on = can_meet && p.rows_per_slice / TM >= 128;
     if (const char* e = getenv("SSMI_MFMA_SYNC")) meet_on = can_meet && e[0] == '1';
     P.xsync = meet_on ? xsync : nullptr;
+    {
+        const char* e = getenv("SSMI_MFMA_FOLD16");
+        P.fold16 = (k <= 16 && !(e && e[0] == '0')) ? 1 : 0;
+    }
     P.xsync_from = 17;
     if (const char* e = getenv("SSMI_MFMA_SYNC_FROM")) P.xsync_from = atoi(e);
     P.xsync_polls = 2048;   // about 2 ms: longer than any fold round

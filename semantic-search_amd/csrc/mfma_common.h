@@ -48,6 +48,7 @@ struct MfmaParams {
     // cycles / real time = the clock the chip held under this launch (ssmi_index_get_kernel_clock)
     unsigned long long* clk;
     int xsync_polls;           // ... bound of one wait, in polls of about a microsecond
+    int fold16;                // k <= 16: the four-queries-per-wave fold (fold_queries16)
     int xsync_from;            // ... they meet from this row tile of their slices on (the first tiles carry the heavy folds)
 #ifdef SSMI_STAMP
     unsigned long long* dbg;   // diagnostic build only: per-wave cycle sums
@@ -335,6 +336,88 @@ __device__ __forceinline__ void fold_queries(int wave, int q0, const MfmaParams&
         if (qn < nql) nxt = fold_load<R>(qn, list_of(qn), P.k, cand + (size_t)qn * CAND_CAP, cnt_l, kept_l);
         fold_one<R>(ql, cur, list_of(ql), P.k, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l, P.thr_floor,
                     P.gtop ? P.gtop + ((size_t)(q0 + ql) * P.nslices + slice) * P.gtop_m : nullptr, P.gtop_m);
+        cur = nxt;
+    }
+}
+
+// The same fold for k <= 16, FOUR queries per wave: a query's list and a chunk of 16 of its candidates live in one
+// row of 16 lanes, so every compare-exchange partner is a DPP move away (no permlane swaps, no ds_bpermute) and one
+// pass of the network serves four queries.  Per chunk: bitonic sort of the 16 candidates (10 stages), element-wise
+// maximum with the mirrored list (the best 16 of the union, as a bitonic sequence), bitonic merge (4 stages).  Wave w
+// takes the queries w, w+8, w+16, ... as fold_queries does (the threshold exchange behind the fold relies on that),
+// four at a time: row g of pass `it` holds query w + 8*(4*it + g).  The next pass's operands are loaded ahead.
+__device__ __forceinline__ skey_t row_mirror64(skey_t v) {
+    const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)(v & 0xFFFFFFFFull), 0x140, 0xF, 0xF, true);  // row_mirror
+    const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(v >> 32), 0x140, 0xF, 0xF, true);
+    return ((skey_t)(unsigned)hi << 32) | (skey_t)(unsigned)lo;
+}
+struct Fold16Operands {
+    int ql;        // the row's query (within the tile), -1: none
+    int n;         // its candidates (clamped to the buffer's capacity)
+    unsigned has;  // it already owns a k-list
+    skey_t list;   // list element lane % 16, best first (0: none)
+    skey_t c;      // candidate lane % 16 of the first chunk
+};
+__device__ __forceinline__ Fold16Operands fold16_load(int it, int wave, int nql, int q0, const MfmaParams& P, int slice,
+                                                      const skey_t* cand, const unsigned* cnt_l, const unsigned* kept_l) {
+    const int lane = lane_id(), j = lane & 15;
+    Fold16Operands o;
+    o.ql = wave + 8 * (4 * it + (lane >> 4));
+    if (o.ql >= nql) o.ql = -1;
+    const int qs = o.ql < 0 ? 0 : o.ql;
+    o.n = o.ql < 0 ? 0 : (int)min(cnt_l[qs], (unsigned)CAND_CAP);
+    o.has = o.ql < 0 ? 1u : kept_l[qs];
+    o.list = (o.ql >= 0 && o.has && j < P.k) ? P.partial[((size_t)(q0 + qs) * P.nslices + slice) * P.k + j] : 0;
+    o.c = (j < o.n) ? cand[(size_t)qs * CAND_CAP + j] : 0;
+    return o;
+}
+__device__ __forceinline__ void fold16_pass(const Fold16Operands& o, int q0, const MfmaParams& P, int slice, const skey_t* cand,
+                                            float* thr_l, unsigned* cnt_l, unsigned* kept_l) {
+    const int lane = lane_id(), j = lane & 15;
+    const bool work = o.ql >= 0 && !(o.n == 0 && o.has);   // nothing new: list and threshold stand
+    if (__builtin_amdgcn_ballot_w64(work) == 0) return;
+    int nmax = o.n;                          // chunks: as many as the longest of the four buffers needs (n is uniform
+    nmax = max(nmax, xor_lane<16>(nmax));    // within a row, so any lane of the other rows will do)
+    nmax = max(nmax, xor_lane<32>(nmax));
+    nmax = __builtin_amdgcn_readfirstlane(nmax);
+    WaveTopK<1> t, c;
+    t.v[0] = o.list;
+    c.v[0] = o.c;
+    const size_t cbase = (size_t)(o.ql < 0 ? 0 : o.ql) * CAND_CAP;
+    for (int base = 0; base < nmax; base += 16) {
+        if (base) c.v[0] = (base + j < o.n) ? cand[cbase + base + j] : 0;
+        c.lane_stages<1>(2);
+        c.lane_stages<2>(4);
+        c.lane_stages<4>(8);
+        c.lane_stages<8>(0);                 // every row best first
+        t.v[0] = kmax(t.v[0], row_mirror64(c.v[0]));
+        t.lane_stages<8>(0);
+    }
+    if (!work) return;
+    const size_t q = (size_t)(q0 + o.ql);
+    if (j < P.k) P.partial[(q * P.nslices + slice) * P.k + j] = t.v[0];
+    if (P.gtop && j < P.gtop_m)
+        __hip_atomic_store(P.gtop + (q * P.nslices + slice) * P.gtop_m + j, (unsigned)(t.v[0] >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (j == 0) {
+        lds_store(&kept_l[o.ql], 1u);
+        lds_store(&cnt_l[o.ql], 0u);
+    }
+    if (j == P.k - 1) {                      // the lane that holds the k-th key raises the threshold
+        const skey_t thrk = t.v[0];
+        lds_store(reinterpret_cast<unsigned*>(&thr_l[o.ql]), __float_as_uint((thrk == 0) ? P.thr_floor : fmaxf(key_score(thrk), P.thr_floor)));
+    }
+}
+__device__ __forceinline__ void fold_queries16(int wave, int q0, const MfmaParams& P, int slice, const skey_t* cand,
+                                               float* thr_l, unsigned* cnt_l, unsigned* kept_l) {
+    int nql = P.nq - q0;
+    if (nql > 256) nql = 256;
+    if (wave >= nql) return;
+    const int passes = (nql - wave + 31) / 32;   // queries w, w+8, ...: four per pass
+    Fold16Operands cur = fold16_load(0, wave, nql, q0, P, slice, cand, cnt_l, kept_l);
+    for (int it = 0; it < passes; ++it) {
+        Fold16Operands nxt = cur;
+        if (it + 1 < passes) nxt = fold16_load(it + 1, wave, nql, q0, P, slice, cand, cnt_l, kept_l);
+        fold16_pass(cur, q0, P, slice, cand, thr_l, cnt_l, kept_l);
         cur = nxt;
     }
 }

@@ -154,8 +154,10 @@ __global__ void __launch_bounds__(512) flat_mfma_n128_kernel(MfmaParams P) {
             __syncthreads();
             ++tiles_done;
             if (((tiles_done & (tiles_done - 1)) == 0 && (tiles_done & 0x55555555u)) || *flag_l) {
-                for (int ql = wave; ql < N128_TN; ql += 8)
-                    if (ql < P.nq) compact_query<R>(ql, ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
+                if (R == 1 && P.fold16) fold_queries16(wave, 0, P, slice, cand, thr_l, cnt_l, kept_l);
+                else
+                    for (int ql = wave; ql < N128_TN; ql += 8)
+                        if (ql < P.nq) compact_query<R>(ql, ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
                 __syncthreads();
                 if (tid == 0) *flag_l = 0;
             }
@@ -164,8 +166,10 @@ __global__ void __launch_bounds__(512) flat_mfma_n128_kernel(MfmaParams P) {
 
     // ---- end of slice: fold what is left; the k-list is the partial result ----
     __syncthreads();
-    for (int ql = wave; ql < N128_TN; ql += 8)
-        if (ql < P.nq) compact_query<R>(ql, ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
+    if (R == 1 && P.fold16) fold_queries16(wave, 0, P, slice, cand, thr_l, cnt_l, kept_l);
+    else
+        for (int ql = wave; ql < N128_TN; ql += 8)
+            if (ql < P.nq) compact_query<R>(ql, ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
 }
 
 hipError_t launch_flat_mfma_n128(const MfmaParams& P, int r, int grid, size_t lds, hipStream_t s) {

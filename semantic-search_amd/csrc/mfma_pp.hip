@@ -381,7 +381,8 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
         }
         if (fold_due) {
 #endif
-            fold_queries<R>(wave, q0, P, slice, cand, thr_l, cnt_l, kept_l);
+            if (R == 1 && P.fold16) fold_queries16(wave, q0, P, slice, cand, thr_l, cnt_l, kept_l);
+            else fold_queries<R>(wave, q0, P, slice, cand, thr_l, cnt_l, kept_l);
             STAMP(5)
             // Share the thresholds between the slices of this query tile: the k-th score of ANY slice is a lower
             // bound of the final k-th score, so every slice may filter with the highest one reached so far (its
@@ -451,7 +452,8 @@ __global__ void __launch_bounds__(512) flat_mfma_pp_kernel(MfmaParams P) {
         }
         return;
     }
-    fold_queries<R>(wave, q0, P, slice, cand, thr_l, cnt_l, kept_l);
+    if (R == 1 && P.fold16) fold_queries16(wave, q0, P, slice, cand, thr_l, cnt_l, kept_l);
+    else fold_queries<R>(wave, q0, P, slice, cand, thr_l, cnt_l, kept_l);
 }
 
 hipError_t launch_flat_mfma_pp(const MfmaParams& P_in, int r, int grid, size_t lds, hipStream_t s) {

@@ -244,8 +244,10 @@ __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
         }
         if (fold_due) {
             __syncthreads();  // drains the candidate stores (and the row stream, once per compaction)
-            for (int ql = wave; ql < N128_TN; ql += 8)
-                if (ql < P.nq) compact_query<R>(ql, ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
+            if (R == 1 && P.fold16) fold_queries16(wave, 0, P, slice, cand, thr_l, cnt_l, kept_l);   // k <= 16: four queries per wave pass
+            else
+                for (int ql = wave; ql < N128_TN; ql += 8)
+                    if (ql < P.nq) compact_query<R>(ql, ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
             // Share the thresholds between the slices (one per CU, a few thousand rows each: a slice's own k-th score
             // stays weak to the end): the k-th score of ANY slice bounds the final k-th score from below, so every
             // slice filters with the highest one reached anywhere.  Same exchange as the 256-query kernel: one
@@ -274,8 +276,10 @@ __global__ void __launch_bounds__(512) flat_mfma_r128_kernel(MfmaParams P) {
 
     // ---- end of slice: fold what is left; the k-list is the partial result ----
     __syncthreads();
-    for (int ql = wave; ql < N128_TN; ql += 8)
-        if (ql < P.nq) compact_query<R>(ql, ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
+    if (R == 1 && P.fold16) fold_queries16(wave, 0, P, slice, cand, thr_l, cnt_l, kept_l);
+    else
+        for (int ql = wave; ql < N128_TN; ql += 8)
+            if (ql < P.nq) compact_query<R>(ql, ql, P, slice, cand + (size_t)ql * CAND_CAP, thr_l, cnt_l, kept_l);
 }
 
 template <int PD, int NT>
