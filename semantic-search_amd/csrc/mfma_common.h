@@ -358,8 +358,10 @@ struct Fold16Operands {
     skey_t list;   // list element lane % 16, best first (0: none)
     skey_t c;      // candidate lane % 16 of the first chunk
 };
-__device__ __forceinline__ Fold16Operands fold16_load(int it, int wave, int nql, int q0, const MfmaParams& P, int slice,
-                                                      const skey_t* cand, const unsigned* cnt_l, const unsigned* kept_l) {
+// list_of(ql): the query's k-list in global memory; tops_of(ql): where it publishes its best gtop_m scores (or nullptr)
+template <class ListOf>
+__device__ __forceinline__ Fold16Operands fold16_load(int it, int wave, int nql, int k, ListOf list_of, const skey_t* cand,
+                                                      const unsigned* cnt_l, const unsigned* kept_l) {
     const int lane = lane_id(), j = lane & 15;
     Fold16Operands o;
     o.ql = wave + 8 * (4 * it + (lane >> 4));
@@ -367,12 +369,13 @@ __device__ __forceinline__ Fold16Operands fold16_load(int it, int wave, int nql,
     const int qs = o.ql < 0 ? 0 : o.ql;
     o.n = o.ql < 0 ? 0 : (int)min(cnt_l[qs], (unsigned)CAND_CAP);
     o.has = o.ql < 0 ? 1u : kept_l[qs];
-    o.list = (o.ql >= 0 && o.has && j < P.k) ? P.partial[((size_t)(q0 + qs) * P.nslices + slice) * P.k + j] : 0;
+    o.list = (o.ql >= 0 && o.has && j < k) ? list_of(qs)[j] : 0;
     o.c = (j < o.n) ? cand[(size_t)qs * CAND_CAP + j] : 0;
     return o;
 }
-__device__ __forceinline__ void fold16_pass(const Fold16Operands& o, int q0, const MfmaParams& P, int slice, const skey_t* cand,
-                                            float* thr_l, unsigned* cnt_l, unsigned* kept_l) {
+template <class ListOf, class TopsOf>
+__device__ __forceinline__ void fold16_pass(const Fold16Operands& o, int k, float thr_floor, ListOf list_of, TopsOf tops_of, int gtop_m,
+                                            const skey_t* cand, float* thr_l, unsigned* cnt_l, unsigned* kept_l) {
     const int lane = lane_id(), j = lane & 15;
     const bool work = o.ql >= 0 && !(o.n == 0 && o.has);   // nothing new: list and threshold stand
     if (__builtin_amdgcn_ballot_w64(work) == 0) return;
@@ -394,32 +397,40 @@ __device__ __forceinline__ void fold16_pass(const Fold16Operands& o, int q0, con
         t.lane_stages<8>(0);
     }
     if (!work) return;
-    const size_t q = (size_t)(q0 + o.ql);
-    if (j < P.k) P.partial[(q * P.nslices + slice) * P.k + j] = t.v[0];
-    if (P.gtop && j < P.gtop_m)
-        __hip_atomic_store(P.gtop + (q * P.nslices + slice) * P.gtop_m + j, (unsigned)(t.v[0] >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (j < k) list_of(o.ql)[j] = t.v[0];
+    unsigned* tops = tops_of(o.ql);
+    if (tops && j < gtop_m) __hip_atomic_store(tops + j, (unsigned)(t.v[0] >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (j == 0) {
         lds_store(&kept_l[o.ql], 1u);
         lds_store(&cnt_l[o.ql], 0u);
     }
-    if (j == P.k - 1) {                      // the lane that holds the k-th key raises the threshold
+    if (j == k - 1) {                        // the lane that holds the k-th key raises the threshold
         const skey_t thrk = t.v[0];
-        lds_store(reinterpret_cast<unsigned*>(&thr_l[o.ql]), __float_as_uint((thrk == 0) ? P.thr_floor : fmaxf(key_score(thrk), P.thr_floor)));
+        lds_store(reinterpret_cast<unsigned*>(&thr_l[o.ql]), __float_as_uint((thrk == 0) ? thr_floor : fmaxf(key_score(thrk), thr_floor)));
     }
 }
+template <class ListOf, class TopsOf>
+__device__ __forceinline__ void fold_lists16(int wave, int nql, int k, float thr_floor, ListOf list_of, TopsOf tops_of, int gtop_m,
+                                             const skey_t* cand, float* thr_l, unsigned* cnt_l, unsigned* kept_l) {
+    if (wave >= nql) return;
+    const int passes = (nql - wave + 31) / 32;   // queries w, w+8, ...: four per pass
+    Fold16Operands cur = fold16_load(0, wave, nql, k, list_of, cand, cnt_l, kept_l);
+    for (int it = 0; it < passes; ++it) {
+        Fold16Operands nxt = cur;
+        if (it + 1 < passes) nxt = fold16_load(it + 1, wave, nql, k, list_of, cand, cnt_l, kept_l);
+        fold16_pass(cur, k, thr_floor, list_of, tops_of, gtop_m, cand, thr_l, cnt_l, kept_l);
+        cur = nxt;
+    }
+}
+// Flat kernels: query q0 + ql of slice `slice` keeps its list at partial[q][slice][k]
 __device__ __forceinline__ void fold_queries16(int wave, int q0, const MfmaParams& P, int slice, const skey_t* cand,
                                                float* thr_l, unsigned* cnt_l, unsigned* kept_l) {
     int nql = P.nq - q0;
     if (nql > 256) nql = 256;
-    if (wave >= nql) return;
-    const int passes = (nql - wave + 31) / 32;   // queries w, w+8, ...: four per pass
-    Fold16Operands cur = fold16_load(0, wave, nql, q0, P, slice, cand, cnt_l, kept_l);
-    for (int it = 0; it < passes; ++it) {
-        Fold16Operands nxt = cur;
-        if (it + 1 < passes) nxt = fold16_load(it + 1, wave, nql, q0, P, slice, cand, cnt_l, kept_l);
-        fold16_pass(cur, q0, P, slice, cand, thr_l, cnt_l, kept_l);
-        cur = nxt;
-    }
+    fold_lists16(wave, nql, P.k, P.thr_floor,
+                 [&](int ql) { return P.partial + ((size_t)(q0 + ql) * P.nslices + slice) * P.k; },
+                 [&](int ql) -> unsigned* { return P.gtop ? P.gtop + ((size_t)(q0 + ql) * P.nslices + slice) * P.gtop_m : nullptr; },
+                 P.gtop_m, cand, thr_l, cnt_l, kept_l);
 }
 
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
